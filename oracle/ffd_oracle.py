@@ -1,0 +1,425 @@
+"""CPU oracle for the fdiff sampling hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch-CPU fp32 / numpy fp64, explicit math, no
+``nn.TransformerEncoder`` / ``nn.LSTM`` / ``torch.fft`` black boxes) of the
+reference algorithm for the path BASELINE.json names.  Every function cites
+the reference file:line it follows (paths relative to /root/reference).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module, and only as the checker / the timed CPU baseline.
+The product package ``fastfourierdiffusion_amd`` never imports it.
+
+Parity pin: ``tests/test_oracle_golden.py`` checks every function below
+against ``tests/golden/*.npz`` -- outputs of the *unmodified* reference run in
+the build container by ``oracle/gen_golden.py`` (script committed), and against
+the reference's own invariants (tests/test_utils.py:36-51 dft/idft round trip,
+tests/test_transformer.py:18-82 encoder known answers).
+
+Third-party arithmetic the reference delegates to torch (2.10.0 here; the
+reference pins none, pyproject.toml:38) is restated from the published
+definitions: ortho rFFT/irFFT (torch.fft docs), post-norm encoder layer with
+ReLU FFN (Vaswani et al. / nn.TransformerEncoderLayer docs), scaled dot product
+attention, LayerNorm eps=1e-5 biased variance, LSTM cell gate order i,f,g,o.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# --------------------------------------------------------------------------
+# P1 / P2 : scheduler tables              (src/fdiff/schedulers/sde.py:42-64)
+# --------------------------------------------------------------------------
+
+
+def noise_scaling(max_len: int, fourier_noise_scaling: bool) -> Tensor:
+    """G in R^L, sde.py:42-60.  Mirrors the fp32 op order exactly:
+    ones * (1/sqrt2) then G[0] *= sqrt2 (-> 0.99999994)."""
+    G = torch.ones(max_len, dtype=torch.float32)
+    if fourier_noise_scaling:
+        G = 1 / (math.sqrt(2)) * G
+        G[0] *= math.sqrt(2)
+        if max_len % 2 == 0:
+            G[max_len // 2] *= math.sqrt(2)
+    return G
+
+
+def timesteps(num_steps: int, eps: float = 1e-5) -> Tuple[Tensor, Tensor]:
+    """sde.py:62-64 -- fp32 linspace(1, eps, N); step_size = t[0]-t[1] (0-dim fp32)."""
+    ts = torch.linspace(1.0, eps, num_steps)
+    return ts, ts[0] - ts[1]
+
+
+def prior(z: Tensor, G: Tensor, sigma_max: Optional[float] = None) -> Tensor:
+    """sde.py:79-87 (VE: 125-127).  x_T = diag(G) @ z  (z is the injected N(0,1)
+    draw of shape (B,L,C)); elementwise here, dense diag matmul there (Q8)."""
+    x = G.view(1, -1, 1) * z
+    if sigma_max is not None:
+        x = sigma_max * x
+    return x
+
+
+# --------------------------------------------------------------------------
+# S1 / S2 : reverse Euler-Maruyama step         (sde.py:129-165, 215-246)
+# --------------------------------------------------------------------------
+
+
+def vp_step(x: Tensor, score: Tensor, z: Tensor, t: float, G: Tensor, step_size: Tensor,
+            beta_min: float = 0.1, beta_max: float = 20.0) -> Tensor:
+    """VPScheduler.step, sde.py:215-246.  ``t`` is the python float obtained by
+    ``timesteps[i].item()`` (fp32 widened to double, sampler.py:96-98).
+    beta is a python double (sde.py:212-213); g = float32(sqrt(beta) * G)
+    (python double * fp32 tensor -> fp32 tensor, sde.py:230)."""
+    beta = beta_min + t * (beta_max - beta_min)
+    g = (math.sqrt(beta) * G).view(1, -1, 1)  # diag of `diffusion`
+    drift = -0.5 * beta * x - (g * g) * score  # sde.py:233-235
+    return x - drift * step_size + torch.sqrt(step_size) * (g * z)  # :240-244
+
+
+def ve_step(x: Tensor, score: Tensor, z: Tensor, t: float, G: Tensor, step_size: Tensor,
+            sigma_min: float = 0.01, sigma_max: float = 50.0) -> Tensor:
+    """VEScheduler.step, sde.py:129-165."""
+    sqrt_derivative = (sigma_min * math.sqrt(2 * math.log(sigma_max / sigma_min))
+                       * (sigma_max / sigma_min) ** t)  # python double, :143-147
+    g = (sqrt_derivative * G).view(1, -1, 1)
+    drift = -((g * g) * score)  # :152-154
+    return x - drift * step_size + torch.sqrt(step_size) * (g * z)  # :159-163
+
+
+# --------------------------------------------------------------------------
+# F1 / F2 : packed ortho rFFT / irFFT      (src/fdiff/utils/fourier.py:8-94)
+# --------------------------------------------------------------------------
+
+
+def _dft_mats(L: int) -> Tuple[np.ndarray, np.ndarray]:
+    n = np.arange(L, dtype=np.float64)
+    k = np.arange(L // 2 + 1, dtype=np.float64)
+    ang = -2.0 * np.pi * np.outer(k, n) / L
+    return np.cos(ang) / math.sqrt(L), np.sin(ang) / math.sqrt(L)
+
+
+def dft(x: Tensor) -> Tensor:
+    """fourier.py:8-52: X = rfft(x, dim=1, norm='ortho'); out = [Re X[0..L//2] ;
+    Im X[1..ceil(L/2)-1]] along dim 1 -> same shape (B,L,C).  The transform
+    itself is restated from its definition X_k = L^-1/2 sum_n x_n e^{-2 pi i k n/L}
+    as an explicit fp64 matrix product rounded once to fp32."""
+    B, L, C = x.shape
+    cr, ci = _dft_mats(L)
+    xd = x.detach().to(torch.float64).numpy()
+    re = np.einsum("kn,bnc->bkc", cr, xd)
+    im = np.einsum("kn,bnc->bkc", ci, xd)
+    n_im_hi = L - (L // 2 + 1) + 1  # Im rows 1 .. L-n_real
+    out = np.concatenate([re, im[:, 1:n_im_hi]], axis=1)
+    assert out.shape == (B, L, C)
+    return torch.from_numpy(out.astype(np.float32))
+
+
+def idft(xt: Tensor) -> Tensor:
+    """fourier.py:55-94: n_real = ceil((L+1)/2); Im padded with 0 at DC (and at
+    Nyquist for even L); x = irfft(X, n=L, norm='ortho').  irfft restated as
+    x_n = L^-1/2 [X_0 + 2 sum_{0<k<L/2} (Re X_k cos - Im X_k sin) (+ X_{L/2}(-1)^n)]."""
+    B, L, C = xt.shape
+    n_real = math.ceil((L + 1) / 2)
+    xd = xt.detach().to(torch.float64).numpy()
+    re = xd[:, :n_real]
+    im = np.zeros_like(re)
+    im[:, 1:1 + (L - n_real)] = xd[:, n_real:]
+    cr, ci = _dft_mats(L)  # cos(-a)/sqrtL , sin(-a)/sqrtL  with a = 2 pi k n / L
+    w = np.full(n_real, 2.0)
+    w[0] = 1.0
+    if L % 2 == 0:
+        w[-1] = 1.0
+    # x_n = sum_k w_k (Re_k cos(a) - Im_k sin(a)) / sqrtL ; ci = -sin(a)/sqrtL
+    out = np.einsum("kn,bkc->bnc", cr * w[:, None], re) + np.einsum("kn,bkc->bnc", ci * w[:, None], im)
+    return torch.from_numpy(out.astype(np.float32))
+
+
+# --------------------------------------------------------------------------
+# M2 / M3 : positional + time encoders     (src/fdiff/models/transformer.py)
+# --------------------------------------------------------------------------
+
+
+def renorm_embedding(weight: Tensor, max_norm: float, max_iter: int = 8) -> Tensor:
+    """transformer.py:13-15 -- nn.Embedding(max_norm=sqrt(d)) renormalises the
+    looked-up rows *in place* on every forward: rows with ||w||_2 > max_norm are
+    scaled by max_norm / (||w|| + 1e-7) (torch embedding_renorm_).  The
+    reference therefore converges to a fixed point after 2-3 lookups (SURVEY
+    Q7); we iterate to that fixed point."""
+    w = weight.detach().clone().to(torch.float32)
+    for _ in range(max_iter):
+        norms = w.norm(2, dim=1)
+        mask = norms > max_norm
+        if not bool(mask.any()):
+            break
+        scale = max_norm / (norms[mask] + 1e-7)
+        w[mask] = w[mask] * scale[:, None]
+    return w
+
+
+def time_embedding(t: Tensor, W: Tensor, dense_w: Tensor, dense_b: Tensor, d_model: int) -> Tensor:
+    """GaussianFourierProjection.forward, transformer.py:77-91.
+    proj = ((t*W)*2)*pi left-to-right in fp32; cat(sin,cos)[:d]; Linear(d,d).
+    Returns (B,d) -- the caller broadcasts over L."""
+    time_proj = t[:, None] * W[None, :] * 2 * np.pi
+    emb = torch.cat([torch.sin(time_proj), torch.cos(time_proj)], dim=-1)[:, :d_model]
+    return F.linear(emb, dense_w, dense_b)
+
+
+# --------------------------------------------------------------------------
+# M4 : post-norm encoder layer (explicit form, cached_transformer.py:125-134)
+# --------------------------------------------------------------------------
+
+
+def _layer_params(sd: Dict[str, Tensor], i: int, prefix: str = "backbone.layers.") -> Dict[str, Tensor]:
+    p = f"{prefix}{i}."
+    return {
+        "in_w": sd[p + "self_attn.in_proj_weight"], "in_b": sd[p + "self_attn.in_proj_bias"],
+        "out_w": sd[p + "self_attn.out_proj.weight"], "out_b": sd[p + "self_attn.out_proj.bias"],
+        "w1": sd[p + "linear1.weight"], "b1": sd[p + "linear1.bias"],
+        "w2": sd[p + "linear2.weight"], "b2": sd[p + "linear2.bias"],
+        "n1w": sd[p + "norm1.weight"], "n1b": sd[p + "norm1.bias"],
+        "n2w": sd[p + "norm2.weight"], "n2b": sd[p + "norm2.bias"],
+    }
+
+
+def _attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    """(B,H,L,hd) x3 -> (B,H,L,hd); cached_transformer.py:309-311:
+    softmax(q k^T / sqrt(hd)) v."""
+    hd = q.shape[-1]
+    s = torch.matmul(q, k.transpose(-2, -1)) / (hd ** 0.5)
+    return torch.matmul(F.softmax(s, dim=-1), v)
+
+
+def _split_heads(x: Tensor, H: int) -> Tensor:
+    B, L, d = x.shape
+    return x.view(B, L, H, d // H).transpose(1, 2)
+
+
+def _post_attention(src: Tensor, attn: Tensor, p: Dict[str, Tensor], eps: float = 1e-5) -> Tensor:
+    """out_proj, +res, LN1, FFN, +res, LN2  (cached_transformer.py:314-327)."""
+    B, H, L, hd = attn.shape
+    d = H * hd
+    a = attn.transpose(1, 2).contiguous().view(B, L, d)
+    a = F.linear(a, p["out_w"], p["out_b"])
+    x = F.layer_norm(src + a, (d,), p["n1w"], p["n1b"], eps)
+    f = F.linear(F.relu(F.linear(x, p["w1"], p["b1"])), p["w2"], p["b2"])
+    return F.layer_norm(x + f, (d,), p["n2w"], p["n2b"], eps)
+
+
+def encoder_layer(src: Tensor, p: Dict[str, Tensor], H: int) -> Tensor:
+    """Standard layer (nn.TransformerEncoderLayer, batch_first, post-norm, relu;
+    score_models.py:61-66; explicit form cached_transformer.py:125-134)."""
+    d = src.shape[-1]
+    qkv = F.linear(src, p["in_w"], p["in_b"])
+    q, k, v = (_split_heads(t, H) for t in qkv.split(d, dim=-1))
+    return _post_attention(src, _attention(q, k, v), p)
+
+
+# --------------------------------------------------------------------------
+# K1-K4 / M5-M7 : E2-CRF gate, KV table and the four layer modes
+# --------------------------------------------------------------------------
+
+
+def gate(step: int, max_len: int, K: int = 5, R: int = 10) -> List[int]:
+    """E2CRFCache.determine_recompute_set, caching.py:131-181 (x_tilde and
+    event_intensity are ignored by the reference).  Sorted list of token ids."""
+    if step == 0:
+        return list(range(max_len))
+    interval = 500 if R < 100 else R
+    k_tokens = min(K, max_len)
+    if step % interval == 0:
+        return list(range(min(2 * k_tokens, max_len)))
+    return []
+
+
+class KVTable:
+    """caching.py:88-91,302-396: k/v tables (NL,H,L,hd) fp32, lazily allocated,
+    holding *batch element 0*'s projections (Q1), plus hit/recompute counters
+    (caching.py:283,299,396)."""
+
+    def __init__(self, num_layers: int, max_len: int):
+        self.num_layers, self.max_len = num_layers, max_len
+        self.k: Optional[Tensor] = None
+        self.v: Optional[Tensor] = None
+        self.valid: Optional[Tensor] = None
+        self.recompute_count = 0
+        self.cache_hit_count = 0
+
+    def store(self, layer: int, tokens: Sequence[int], k: Tensor, v: Tensor) -> None:
+        k0, v0 = k[0], v[0]  # batch element 0 (caching.py:326-328)
+        if self.k is None:
+            H, _, hd = k0.shape
+            self.k = torch.zeros(self.num_layers, H, self.max_len, hd)
+            self.v = torch.zeros(self.num_layers, H, self.max_len, hd)
+            self.valid = torch.zeros(self.num_layers, self.max_len, dtype=torch.bool)
+        idx = list(tokens)
+        self.k[layer][:, idx, :] = k0
+        self.v[layer][:, idx, :] = v0
+        self.valid[layer, idx] = True
+        self.recompute_count += len(idx)
+
+    def load(self, layer: int, tokens: Sequence[int]) -> Tuple[Tensor, Tensor]:
+        idx = list(tokens)
+        self.cache_hit_count += len(idx)
+        return self.k[layer][:, idx, :], self.v[layer][:, idx, :]
+
+
+def cached_layer(src: Tensor, p: Dict[str, Tensor], H: int, layer: int, table: KVTable,
+                 recompute: Sequence[int]) -> Tensor:
+    """CachedTransformerEncoderLayer.forward, cached_transformer.py:106-329."""
+    B, L, d = src.shape
+    n = len(recompute)
+    wq, wk, wv = p["in_w"].split(d, dim=0)
+    bq, bk, bv = p["in_b"].split(d, dim=0)
+    if n == L:
+        # :142-191  standard layer, then K,V = W_{k,v} * (layer OUTPUT) (Q2), store elem 0
+        out = encoder_layer(src, p, H)
+        k_all = _split_heads(F.linear(out, wk, bk), H)
+        v_all = _split_heads(F.linear(out, wv, bv), H)
+        table.store(layer, range(L), k_all, v_all)
+        return out
+    if n > 0.8 * L:
+        # :196-220  standard layer, no store
+        return encoder_layer(src, p, H)
+    q = _split_heads(F.linear(src, wq, bq), H)  # :228-234
+    if n == 0:
+        # :237-251  K,V = table broadcast over the batch
+        k_c, v_c = table.load(layer, range(L))
+        k_full = k_c.unsqueeze(0).expand(B, -1, -1, -1)
+        v_full = v_c.unsqueeze(0).expand(B, -1, -1, -1)
+    else:
+        # :259-305  cached rows U recomputed rows (from the layer INPUT, per sample)
+        rec = sorted(recompute)
+        cached = sorted(set(range(L)) - set(rec))
+        hd = d // H
+        k_full = torch.zeros(B, H, L, hd)
+        v_full = torch.zeros(B, H, L, hd)
+        if cached:
+            k_c, v_c = table.load(layer, cached)
+            k_full[:, :, cached, :] = k_c.unsqueeze(0)
+            v_full[:, :, cached, :] = v_c.unsqueeze(0)
+        src_r = src[:, rec, :]
+        k_r = F.linear(src_r, wk, bk).view(B, len(rec), H, hd).transpose(1, 2)
+        v_r = F.linear(src_r, wv, bv).view(B, len(rec), H, hd).transpose(1, 2)
+        k_full[:, :, rec, :] = k_r
+        v_full[:, :, rec, :] = v_r
+        table.store(layer, rec, k_r, v_r)
+    return _post_attention(src, _attention(q, k_full, v_full), p)
+
+
+# --------------------------------------------------------------------------
+# M1 / M6 / M8 : score models             (src/fdiff/models/score_models.py)
+# --------------------------------------------------------------------------
+
+
+def _embed(x: Tensor, t: Tensor, sd: Dict[str, Tensor], d: int, with_pos: bool) -> Tensor:
+    h = F.linear(x, sd["embedder.weight"], sd["embedder.bias"])  # score_models.py:96
+    if with_pos:
+        pos = renorm_embedding(sd["pos_encoder.embedding.weight"], math.sqrt(d))
+        h = h + pos[None, : x.shape[1], :]  # :99, transformer.py:26-28
+    temb = time_embedding(t, sd["time_encoder.W"], sd["time_encoder.dense.weight"],
+                          sd["time_encoder.dense.bias"], d)
+    return h + temb[:, None, :]  # :102
+
+
+def score_forward(x: Tensor, t: Tensor, sd: Dict[str, Tensor], num_layers: int, n_head: int,
+                  table: Optional[KVTable] = None, recompute: Optional[Sequence[int]] = None,
+                  return_crf: bool = False):
+    """ScoreModule.forward (+ _forward_with_cache), score_models.py:79-194.
+    x (B,L,C) fp32, t (B,) fp32 all equal.  ``table``/``recompute`` select the
+    cached path exactly as ``use_cache and recompute_tokens is not None`` does."""
+    d = sd["embedder.weight"].shape[0]
+    h = _embed(x, t, sd, d, with_pos=True)
+    crf = []
+    for i in range(num_layers):
+        p = _layer_params(sd, i)
+        if table is not None and recompute is not None:
+            h = cached_layer(h, p, n_head, i, table, recompute)
+            crf.append(h[0])  # score_models.py:181-194
+        else:
+            h = encoder_layer(h, p, n_head)
+    score = F.linear(h, sd["unembedder.weight"], sd["unembedder.bias"])  # :113
+    if return_crf:
+        return score, (torch.stack(crf, 0) if crf else None)
+    return score
+
+
+def lstm_layer(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor) -> Tensor:
+    """nn.LSTM(d,d,batch_first) forward with zero initial state; gate order
+    i,f,g,o (torch docs); c' = f*c + i*g ; h' = o*tanh(c')."""
+    B, L, d = x.shape
+    h = torch.zeros(B, d)
+    c = torch.zeros(B, d)
+    gx = F.linear(x, w_ih, b_ih)  # (B,L,4d)
+    outs = []
+    for s in range(L):
+        g = gx[:, s] + F.linear(h, w_hh, b_hh)
+        i, f, gg, o = g.split(d, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs, 1)
+
+
+def lstm_score_forward(x: Tensor, t: Tensor, sd: Dict[str, Tensor], num_layers: int) -> Tensor:
+    """LSTMScoreModule.forward, score_models.py:486-511 (no positional encoding,
+    residual LSTM stack)."""
+    d = sd["embedder.weight"].shape[0]
+    h = _embed(x, t, sd, d, with_pos=False)
+    for i in range(num_layers):
+        p = f"backbone.{i}."
+        h = h + lstm_layer(h, sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"],
+                           sd[p + "bias_ih_l0"], sd[p + "bias_hh_l0"])
+    return F.linear(h, sd["unembedder.weight"], sd["unembedder.bias"])
+
+
+# --------------------------------------------------------------------------
+# L1 : the sampling loop with injected noise  (src/fdiff/sampling/sampler.py)
+# --------------------------------------------------------------------------
+
+
+def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, num_layers: int,
+           n_head: int, sde: str, sde_kwargs: Dict[str, float], fourier_noise_scaling: bool,
+           num_samples: int, batch_size: int, num_steps: int, noise: Iterable[Tensor],
+           use_cache: bool = False, K: int = 5, R: int = 10, eps: float = 1e-5) -> Tensor:
+    """DiffusionSampler.sample, sampler.py:105-215, with the N(0,1) draws taken
+    from ``noise`` in call order (one (B,L,C) tensor for the prior of each
+    batch, then one per step) instead of torch's CPU generator.
+    Reproduces Q3 (cache reset only for batch 0; global_step keeps counting)
+    and Q10 (num_batches = max(1, num_samples // batch_size))."""
+    G = noise_scaling(max_len, fourier_noise_scaling)
+    ts, step_size = timesteps(num_steps, eps)
+    noise = iter(noise)
+    num_batches = max(1, num_samples // batch_size)
+    table: Optional[KVTable] = None
+    global_step = 0
+    out = []
+    for b in range(num_batches):
+        bs = min(num_samples - b * batch_size, batch_size)
+        z0 = next(noise)
+        assert z0.shape == (bs, max_len, n_channels)
+        x = prior(z0, G, sde_kwargs["sigma_max"] if sde == "ve" else None)
+        if use_cache and b == 0:
+            table = KVTable(num_layers, max_len)
+            global_step = 0
+        for i in range(num_steps):
+            t_val = ts[i].item()
+            t = torch.full((bs,), t_val, dtype=torch.float32)
+            rec = gate(global_step, max_len, K, R) if use_cache else None
+            if kind == "lstm":
+                score = lstm_score_forward(x, t, sd, num_layers)
+            else:
+                score = score_forward(x, t, sd, num_layers, n_head, table if use_cache else None, rec)
+            z = next(noise)
+            if sde == "vp":
+                x = vp_step(x, score, z, t_val, G, step_size, **sde_kwargs)
+            else:
+                x = ve_step(x, score, z, t_val, G, step_size, **sde_kwargs)
+            global_step += 1
+        out.append(x)
+    return torch.cat(out, 0)

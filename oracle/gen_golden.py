@@ -1,0 +1,216 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (where /root/reference
+is mounted):   python oracle/gen_golden.py
+Nothing from the reference is copied: this script imports it from where it
+lies (oracle/_ref_import.py) and stores *data* -- expected outputs for seeded
+inputs that the tests regenerate from the same seeds
+(fastfourierdiffusion_amd.utils.synthetic).
+
+N(0,1) draws are injected: torch.randn / torch.randn_like are patched during
+reference sampling to pop from a recorded numpy stream, because torch's CPU
+generator stream cannot be reproduced on the device.
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+from contextlib import contextmanager
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle._ref_import import import_reference  # noqa: E402
+from oracle import cases  # noqa: E402
+from fastfourierdiffusion_amd.utils import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def to_t(sd):
+    return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+
+
+@contextmanager
+def injected_noise(stream):
+    """Patch torch.randn / randn_like to read from ``stream`` (iterator of np arrays)."""
+    orig_randn, orig_like = torch.randn, torch.randn_like
+
+    def randn(*shape, **kw):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        z = next(stream)
+        assert tuple(z.shape) == tuple(shape), (z.shape, shape)
+        return torch.from_numpy(z.copy())
+
+    def randn_like(t, **kw):
+        z = next(stream)
+        assert tuple(z.shape) == tuple(t.shape), (z.shape, t.shape)
+        return torch.from_numpy(z.copy()).to(t.device)
+
+    torch.randn, torch.randn_like = randn, randn_like
+    try:
+        yield
+    finally:
+        torch.randn, torch.randn_like = orig_randn, orig_like
+
+
+def make_scheduler(ns, c):
+    if c["sde"] == "vp":
+        s = ns.VPScheduler(fourier_noise_scaling=c["fourier"], **c["sde_kwargs"])
+    else:
+        s = ns.VEScheduler(fourier_noise_scaling=c["fourier"], **c["sde_kwargs"])
+    s.set_noise_scaling(c["L"])
+    return s
+
+
+def make_model(ns, c):
+    """Reference model with build-generated weights, warmed to the Q7 fixed point."""
+    sch = make_scheduler(ns, c)
+    if c["kind"] == "lstm":
+        m = ns.LSTMScoreModule(n_channels=c["C"], max_len=c["L"], noise_scheduler=sch,
+                               fourier_noise_scaling=c["fourier"], d_model=c["d"], num_layers=c["NL"])
+        sd = synthetic.lstm_state_dict(c["C"], c["L"], c["d"], c["NL"], seed=c["wseed"])
+    else:
+        m = ns.ScoreModule(n_channels=c["C"], max_len=c["L"], noise_scheduler=sch,
+                           fourier_noise_scaling=c["fourier"], d_model=c["d"], num_layers=c["NL"],
+                           n_head=c["H"])
+        sd = synthetic.transformer_state_dict(c["C"], c["L"], c["d"], c["NL"], seed=c["wseed"])
+    missing, unexpected = m.load_state_dict(to_t(sd), strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("cached_backbone") for k in missing), missing
+    m.eval()
+    if c["kind"] != "lstm":
+        with torch.no_grad():
+            for _ in range(4):  # Q7: embedding max_norm renorm reaches its fixed point
+                m.pos_encoder(torch.zeros(1, c["L"], c["d"]))
+    return m, sch
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    ns = import_reference()
+    torch.set_num_threads(8)
+    meta = {"torch": torch.__version__}
+
+    # ---- G1: dft / idft -------------------------------------------------
+    g = {}
+    for (L, C, B, seed) in cases.FFT_CASES:
+        x = next(synthetic.noise_stream((B, L, C), 1, seed))
+        xt = torch.from_numpy(x)
+        g[f"dft_L{L}_C{C}"] = ns.dft(xt).numpy()
+        g[f"idft_L{L}_C{C}"] = ns.idft(xt).numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_fft.npz"), **g)
+
+    # ---- G2: scheduler tables -------------------------------------------
+    g = {}
+    for L in cases.TABLE_LENS:
+        for fourier in (False, True):
+            s = ns.VPScheduler(fourier_noise_scaling=fourier)
+            s.set_noise_scaling(L)
+            g[f"G_L{L}_f{int(fourier)}"] = s.G.numpy()
+    for N in cases.TABLE_STEPS:
+        s = ns.VPScheduler()
+        s.set_timesteps(N)
+        g[f"ts_N{N}"] = s.timesteps.numpy()
+        g[f"dt_N{N}"] = s.step_size.numpy()
+    np.savez_compressed(os.path.join(OUT, "g2_tables.npz"), **g)
+
+    # ---- G3: VP / VE reverse step with injected z -----------------------
+    g = {}
+    for c in cases.STEP_CASES:
+        sch = make_scheduler(ns, c)
+        sch.set_timesteps(c["N"])
+        B, L, C = c["B"], c["L"], c["C"]
+        st = synthetic.noise_stream((B, L, C), 3, c["seed"])
+        x, s, z = (torch.from_numpy(a) for a in st)
+        for i in c["idx"]:
+            t = sch.timesteps[i].item()
+            with injected_noise(iter([z.numpy()])):
+                out = sch.step(model_output=s, timestep=t, sample=x).prev_sample
+            g[f"{c['name']}_i{i}"] = out.numpy()
+        with injected_noise(iter([z.numpy()])):
+            g[f"{c['name']}_prior"] = sch.prior_sampling((B, L, C)).numpy()
+    np.savez_compressed(os.path.join(OUT, "g3_steps.npz"), **g)
+
+    # ---- G4..G8: models --------------------------------------------------
+    g = {}
+    for c in cases.MODEL_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C = c["B"], c["L"], c["C"]
+        name = c["name"]
+        if c["kind"] != "lstm":
+            g[f"{name}_pos_fixed"] = m.pos_encoder.embedding.weight.detach().numpy().copy()
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+        with torch.no_grad():
+            for tv in c["t_values"]:
+                t = torch.full((B,), tv, dtype=torch.float32)
+                # G4: time encoder known answer (added to zeros)
+                te = m.time_encoder(torch.zeros(B, 1, c["d"]), t)
+                g[f"{name}_temb_t{tv}"] = te[:, 0, :].numpy()
+                batch = ns.DiffusableBatch(X=x, y=None, timesteps=t)
+                g[f"{name}_score_t{tv}"] = m(batch).numpy()  # G5 / G8
+            if c.get("cache_seq"):
+                # G6: cached forward sequence through the reference's own modes
+                m.enable_caching(**c.get("cache_kwargs", {}))
+                m.eval()
+                m.cache.reset()
+                tv = c["t_values"][0]
+                t = torch.full((B,), tv, dtype=torch.float32)
+                for j, rec in enumerate(c["cache_seq"]):
+                    xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"] + 100 + j)))
+                    batch = ns.DiffusableBatch(X=xj, y=None, timesteps=t)
+                    sc, crf = m(batch, recompute_tokens=set(rec), step=j, return_crf=True)
+                    g[f"{name}_cseq{j}_score"] = sc.numpy()
+                    if c.get("dump_table"):
+                        g[f"{name}_cseq{j}_k"] = m.cache.k_cache_tensor.numpy().copy()
+                        g[f"{name}_cseq{j}_v"] = m.cache.v_cache_tensor.numpy().copy()
+                        g[f"{name}_cseq{j}_crf"] = crf.numpy().copy()
+                    else:
+                        g[f"{name}_cseq{j}_k_l0h0"] = m.cache.k_cache_tensor[0, 0].numpy().copy()
+                        g[f"{name}_cseq{j}_v_lNhN"] = m.cache.v_cache_tensor[-1, -1].numpy().copy()
+                st = m.cache.get_cache_stats()
+                g[f"{name}_cstats"] = np.array([st["recompute_count"], st["cache_hit_count"]], dtype=np.int64)
+                m.disable_caching()
+    np.savez_compressed(os.path.join(OUT, "g5_models.npz"), **g)
+
+    # ---- G7: trajectories with injected noise ---------------------------
+    g = {}
+    for c in cases.TRAJ_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+        nb = max(1, c["num_samples"] // B)
+        stream = synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"])
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
+                                      cache_kwargs=dict(c.get("cache_kwargs", {})))
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        g[c["name"]] = out.numpy()
+        print(c["name"], out.shape, float(out.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "g7_traj.npz"), **g)
+
+    # ---- G9: gate schedule ------------------------------------------------
+    g = {}
+    for (K, R, L, steps) in cases.GATE_CASES:
+        cache = ns.E2CRFCache(num_layers=1, max_len=L, device=torch.device("cpu"), K=K, R=R)
+        sizes = np.array([len(cache.determine_recompute_set(None, 0.1, s)) for s in steps], dtype=np.int64)
+        first = np.array([sorted(cache.determine_recompute_set(None, 0.1, s))[:1] or [-1] for s in steps],
+                         dtype=np.int64).ravel()
+        g[f"gate_K{K}_R{R}_L{L}_sizes"] = sizes
+        g[f"gate_K{K}_R{R}_L{L}_first"] = first
+    np.savez_compressed(os.path.join(OUT, "g9_gate.npz"), **g)
+
+    with open(os.path.join(OUT, "META.txt"), "w") as f:
+        f.write("generated by oracle/gen_golden.py from the unmodified reference at /root/reference\n")
+        for k, v in meta.items():
+            f.write(f"{k}: {v}\n")
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+"""Pin the CPU oracle (oracle/ffd_oracle.py) against the reference's outputs.
+
+The .npz files under tests/golden were produced by oracle/gen_golden.py, which
+runs the unmodified reference on the seeded inputs regenerated here.  Also
+restates the two numeric invariants the reference's own tests hold for this
+path: the dft/idft round trip (tests/test_utils.py:36-51, atol 1e-5) and the
+encoder known answers (tests/test_transformer.py:18-82, atol 1e-5).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from fastfourierdiffusion_amd.utils import synthetic
+from oracle import cases
+from oracle import ffd_oracle as O
+
+
+def to_t(sd):
+    return {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+
+
+def make_sd(c):
+    if c["kind"] == "lstm":
+        return to_t(synthetic.lstm_state_dict(c["C"], c["L"], c["d"], c["NL"], seed=c["wseed"]))
+    return to_t(synthetic.transformer_state_dict(c["C"], c["L"], c["d"], c["NL"], seed=c["wseed"]))
+
+
+# single-kernel tolerance: <= 1e-6 relative to the output max-norm
+TOL_KERNEL = 2e-6
+# trajectory tolerance: <= 1e-5 relative max-norm at up to 1000 steps
+TOL_TRAJ = 1e-5
+
+
+@pytest.mark.parametrize("case", cases.FFT_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
+def test_fft_golden(golden, case):
+    L, C, B, seed = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
+    g = golden["g1_fft"]
+    assert rel_err(O.dft(x), g[f"dft_L{L}_C{C}"]) < TOL_KERNEL
+    assert rel_err(O.idft(x), g[f"idft_L{L}_C{C}"]) < TOL_KERNEL
+
+
+def test_fft_roundtrip_reference_invariant():
+    # tests/test_utils.py:36-51 (B=100, C=3, L=100/101, atol=1e-5)
+    rng = np.random.default_rng(0)
+    for L in (100, 101):
+        x = torch.from_numpy(rng.standard_normal((100, L, 3)).astype(np.float32))
+        assert torch.allclose(x, O.idft(O.dft(x)), atol=1e-5)
+        assert torch.allclose(x, O.dft(O.idft(x)), atol=1e-5)
+
+
+def test_tables_golden(golden):
+    g = golden["g2_tables"]
+    for L in cases.TABLE_LENS:
+        for f in (False, True):
+            np.testing.assert_array_equal(O.noise_scaling(L, f).numpy(), g[f"G_L{L}_f{int(f)}"])
+    for N in cases.TABLE_STEPS:
+        ts, dt = O.timesteps(N)
+        np.testing.assert_array_equal(ts.numpy(), g[f"ts_N{N}"])
+        np.testing.assert_array_equal(dt.numpy(), g[f"dt_N{N}"])
+
+
+@pytest.mark.parametrize("c", cases.STEP_CASES, ids=lambda c: c["name"])
+def test_step_golden(golden, c):
+    g = golden["g3_steps"]
+    B, L, C = c["B"], c["L"], c["C"]
+    x, s, z = (torch.from_numpy(a) for a in synthetic.noise_stream((B, L, C), 3, c["seed"]))
+    G = O.noise_scaling(L, c["fourier"])
+    ts, dt = O.timesteps(c["N"])
+    for i in c["idx"]:
+        t = ts[i].item()
+        out = (O.vp_step if c["sde"] == "vp" else O.ve_step)(x, s, z, t, G, dt, **c["sde_kwargs"])
+        # Q8: elementwise restatement vs the reference's diag-matmul form: <= a few ulp
+        assert rel_err(out, g[f"{c['name']}_i{i}"]) < 5e-7
+    pr = O.prior(z, G, c["sde_kwargs"].get("sigma_max") if c["sde"] == "ve" else None)
+    assert rel_err(pr, g[f"{c['name']}_prior"]) < 5e-7
+
+
+@pytest.mark.parametrize("c", cases.MODEL_CASES, ids=lambda c: c["name"])
+def test_model_golden(golden, c):
+    g = golden["g5_models"]
+    sd = make_sd(c)
+    B, L, C, d = c["B"], c["L"], c["C"], c["d"]
+    name = c["name"]
+    if c["kind"] != "lstm":
+        pos = O.renorm_embedding(sd["pos_encoder.embedding.weight"], math.sqrt(d))
+        np.testing.assert_allclose(pos.numpy(), g[f"{name}_pos_fixed"], rtol=0, atol=1e-6)
+        # tests/test_transformer.py:29 max_norm invariant
+        assert float((pos ** 2).sum(-1).max()) <= d + 1e-5
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+    for tv in c["t_values"]:
+        t = torch.full((B,), tv, dtype=torch.float32)
+        temb = O.time_embedding(t, sd["time_encoder.W"], sd["time_encoder.dense.weight"],
+                                sd["time_encoder.dense.bias"], d)
+        np.testing.assert_allclose(temb.numpy(), g[f"{name}_temb_t{tv}"], rtol=0, atol=1e-5)
+        if c["kind"] == "lstm":
+            sc = O.lstm_score_forward(x, t, sd, c["NL"])
+        else:
+            sc = O.score_forward(x, t, sd, c["NL"], c["H"])
+        assert rel_err(sc, g[f"{name}_score_t{tv}"]) < TOL_KERNEL * 5
+    if c.get("cache_seq"):
+        table = O.KVTable(c["NL"], L)
+        t = torch.full((B,), c["t_values"][0], dtype=torch.float32)
+        for j, rec in enumerate(c["cache_seq"]):
+            xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"] + 100 + j)))
+            sc, crf = O.score_forward(xj, t, sd, c["NL"], c["H"], table, rec, return_crf=True)
+            assert rel_err(sc, g[f"{name}_cseq{j}_score"]) < TOL_KERNEL * 5, j
+            if c.get("dump_table"):
+                assert rel_err(table.k, g[f"{name}_cseq{j}_k"]) < TOL_KERNEL * 5
+                assert rel_err(table.v, g[f"{name}_cseq{j}_v"]) < TOL_KERNEL * 5
+                assert rel_err(crf, g[f"{name}_cseq{j}_crf"]) < TOL_KERNEL * 5
+            else:
+                assert rel_err(table.k[0, 0], g[f"{name}_cseq{j}_k_l0h0"]) < TOL_KERNEL * 5
+                assert rel_err(table.v[-1, -1], g[f"{name}_cseq{j}_v_lNhN"]) < TOL_KERNEL * 5
+        np.testing.assert_array_equal(
+            np.array([table.recompute_count, table.cache_hit_count]), g[f"{name}_cstats"])
+
+
+_FAST_TRAJ = [c for c in cases.TRAJ_CASES if c["N"] * (c["d"] // 24) <= 400]
+_SLOW_TRAJ = [c for c in cases.TRAJ_CASES if c not in _FAST_TRAJ]
+
+
+def _run_traj(golden, c):
+    sd = make_sd(c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    ck = c.get("cache_kwargs", {})
+    out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"],
+                   sde=c["sde"], sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"],
+                   num_samples=c["num_samples"], batch_size=B, num_steps=N, noise=noise,
+                   use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10))
+    ref = golden["g7_traj"][c["name"]]
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("c", _FAST_TRAJ, ids=lambda c: c["name"])
+def test_traj_golden(golden, c):
+    _run_traj(golden, c)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("c", _SLOW_TRAJ, ids=lambda c: c["name"])
+def test_traj_golden_1000(golden, c):
+    torch.set_num_threads(8)
+    _run_traj(golden, c)
+
+
+@pytest.mark.parametrize("case", cases.GATE_CASES, ids=lambda c: f"K{c[0]}R{c[1]}L{c[2]}")
+def test_gate_golden(golden, case):
+    K, R, L, steps = case
+    g = golden["g9_gate"]
+    sizes = [len(O.gate(s, L, K, R)) for s in steps]
+    first = [(O.gate(s, L, K, R)[:1] or [-1])[0] for s in steps]
+    np.testing.assert_array_equal(sizes, g[f"gate_K{K}_R{R}_L{L}_sizes"])
+    np.testing.assert_array_equal(first, g[f"gate_K{K}_R{R}_L{L}_first"])
