@@ -1,0 +1,707 @@
+// libffd C ABI (include/ffd.h): context, weights, forward orchestration, E2-CRF cache
+// state machine and the sampling loop.  Host code only launches kernels; there is no
+// CPU compute path -- every entry point that needs the device fails loudly without one.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/ffd.h"
+#include "ffd_internal.h"
+
+using namespace ffd;
+
+namespace {
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t n = 0;
+};
+
+struct LstmLayer {
+  const float *wih, *whh, *bih, *bhh;
+  float *wih_p, *bsum;
+};
+
+struct LayerPacked {
+  float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p;
+};
+
+__global__ void k_add_vec(const float* a, const float* b, float* o, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+__global__ void k_fill_hash(float* p, size_t n, uint32_t seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint32_t h = (uint32_t)i * 2654435761u ^ seed;
+    h ^= h >> 16, h *= 0x85ebca6bu, h ^= h >> 13, h *= 0xc2b2ae35u, h ^= h >> 16;
+    p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f)) - 1.0f;  // uniform [-1, 1)
+  }
+}
+
+}  // namespace
+
+struct ffd_ctx {
+  ffd_model_desc desc{};
+  int device = 0;
+  std::string err;
+  std::map<std::string, DevBuf> raw;
+  std::vector<void*> owned;  // packed / table / workspace allocations
+  bool finalized = false;
+  std::vector<LayerWeights> layers;
+  std::vector<LayerPacked> packed;
+  std::vector<LstmLayer> lstm;
+  float* G_dev = nullptr;
+  std::vector<float> G_host;
+  // workspace
+  int ws_B = 0;
+  float *h0 = nullptr, *h1 = nullptr, *qkv = nullptr, *attn = nullptr, *score = nullptr, *kvtmp = nullptr;
+  float *temb1 = nullptr, *temb_tab = nullptr, *ts_dev = nullptr;
+  int temb_cap = 0;
+  std::vector<float> ts_host;
+  long weight_epoch = 0, temb_epoch = -1;
+  float* bench_x = nullptr;
+  int bench_B = 0;
+  // cache
+  bool cache_enabled = false;
+  ffd_cache_cfg ccfg{5, 10};
+  float *kt = nullptr, *vt = nullptr;
+  bool table_allocated = false;
+  ffd_cache_stats stats{};
+
+  int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    err = buf;
+    return code;
+  }
+  int d() const { return desc.d_model; }
+  int hd() const { return desc.d_model / desc.n_head; }
+  size_t table_floats() const { return (size_t)desc.num_layers * desc.n_head * desc.max_len * hd(); }
+};
+
+#define HIPCHECK(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess)                                                                      \
+      return ctx->fail(FFD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
+  *p = nullptr;
+  hipError_t e = hipMalloc((void**)p, nfloats * sizeof(float) + 256);
+  if (e != hipSuccess) return ctx->fail(FFD_ERR_NOMEM, "hipMalloc(%zu floats) failed: %s", nfloats, hipGetErrorString(e));
+  ctx->owned.push_back(*p);
+  return FFD_OK;
+}
+
+static bool d_supported(int d) { return d == 24 || d == 60 || d == 72; }
+static bool hd_supported(int hd) { return hd == 4 || hd == 5 || hd == 6 || hd == 8; }
+
+extern "C" {
+
+const char* ffd_version(void) { return "libffd 0.1 (gfx950, fp32 MFMA 16x16x4, wave64)"; }
+
+const char* ffd_last_error(const ffd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ffd_host_noise_scaling(int max_len, int fourier_noise_scaling, float* G) {
+  if (max_len < 1 || !G) return FFD_ERR_INVALID;
+  // sde.py:49-58 in fp32: ones * (1/sqrt2); G[0] *= sqrt2; (even L) G[L/2] *= sqrt2
+  for (int i = 0; i < max_len; ++i) G[i] = 1.0f;
+  if (fourier_noise_scaling) {
+    const float c = (float)(1.0 / sqrt(2.0));
+    const float s2 = (float)sqrt(2.0);
+    for (int i = 0; i < max_len; ++i) G[i] = c * G[i];
+    G[0] = G[0] * s2;
+    if (max_len % 2 == 0) G[max_len / 2] = G[max_len / 2] * s2;
+  }
+  return FFD_OK;
+}
+
+int ffd_host_timesteps(int n, double eps, float* ts, float* step_size) {
+  if (n < 2 || !ts) return FFD_ERR_INVALID;
+  // torch.linspace(1.0, eps, n) fp32 (scalar form of ATen's linspace kernel):
+  // step = (end - start)/(n-1); idx < n/2 ? start + step*idx : end - step*(n-idx-1)
+  const float start = 1.0f, end = (float)eps;
+  const float step = (end - start) / (float)(n - 1);
+  const int half = n / 2;
+  for (int i = 0; i < n; ++i) {
+    volatile float prod = (i < half) ? step * (float)i : step * (float)(n - i - 1);
+    ts[i] = (i < half) ? start + prod : end - prod;
+  }
+  if (step_size) *step_size = ts[0] - ts[1];
+  return FFD_OK;
+}
+
+int ffd_host_gate(int step, int max_len, int K, int R) {
+  // caching.py:131-181
+  if (step == 0) return max_len;
+  const int interval = (R < 100) ? 500 : R;
+  const int k_tokens = K < max_len ? K : max_len;
+  if (step % interval == 0) {
+    int n = 2 * k_tokens;
+    if (n > max_len) n = max_len;
+    return n < 0 ? 0 : n;
+  }
+  return 0;
+}
+
+int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
+  if (!out || !desc) return FFD_ERR_INVALID;
+  *out = nullptr;
+  ffd_ctx* ctx = new ffd_ctx();
+  ctx->desc = *desc;
+  ctx->device = device;
+  *out = ctx;  // returned even on failure so the caller can read the message
+  const ffd_model_desc& m = ctx->desc;
+  if (m.n_channels < 1 || m.max_len < 1 || m.num_layers < 1)
+    return ctx->fail(FFD_ERR_INVALID, "bad shape: C=%d L=%d NL=%d", m.n_channels, m.max_len, m.num_layers);
+  if (!d_supported(m.d_model))
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "d_model=%d: this build has kernels for d_model in {24, 60, 72}", m.d_model);
+  if (m.kind == FFD_MODEL_TRANSFORMER) {
+    if (m.n_head < 1 || m.d_model % m.n_head != 0)
+      return ctx->fail(FFD_ERR_INVALID, "d_model=%d not divisible by n_head=%d", m.d_model, m.n_head);
+    if (!hd_supported(m.d_model / m.n_head))
+      return ctx->fail(FFD_ERR_UNSUPPORTED, "head_dim=%d: supported head dims are 4, 5, 6, 8", m.d_model / m.n_head);
+    if (m.dim_feedforward < 64 || m.dim_feedforward % 64 != 0)
+      return ctx->fail(FFD_ERR_UNSUPPORTED, "dim_feedforward=%d must be a positive multiple of 64", m.dim_feedforward);
+    if (m.max_len > 512) return ctx->fail(FFD_ERR_UNSUPPORTED, "max_len=%d > 512 (attention kernel limit)", m.max_len);
+  } else if (m.kind != FFD_MODEL_LSTM) {
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "model kind %d", m.kind);
+  }
+  if (m.sde != FFD_SDE_VP && m.sde != FFD_SDE_VE) return ctx->fail(FFD_ERR_UNSUPPORTED, "sde kind %d", m.sde);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return ctx->fail(FFD_ERR_HIP, "no HIP device available (%s): libffd has no CPU path",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return ctx->fail(FFD_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  HIPCHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "device %d is %s; libffd is built for gfx950 only", device, prop.gcnArchName);
+  ctx->G_host.resize(m.max_len);
+  ffd_host_noise_scaling(m.max_len, m.fourier_noise_scaling, ctx->G_host.data());
+  int rc = dev_alloc(ctx, &ctx->G_dev, m.max_len);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpy(ctx->G_dev, ctx->G_host.data(), sizeof(float) * m.max_len, hipMemcpyHostToDevice));
+  rc = dev_alloc(ctx, &ctx->temb1, m.d_model);
+  if (rc) return rc;
+  return FFD_OK;
+}
+
+void ffd_destroy(ffd_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
+  for (void* p : ctx->owned) (void)hipFree(p);
+  delete ctx;
+}
+
+// ---------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------
+static void expected_weights(const ffd_model_desc& m, std::vector<std::pair<std::string, size_t>>& out) {
+  const size_t d = m.d_model, C = m.n_channels, L = m.max_len, F = m.dim_feedforward;
+  if (m.kind == FFD_MODEL_TRANSFORMER) out.push_back({"pos_encoder.embedding.weight", L * d});
+  out.push_back({"time_encoder.W", (d + 1) / 2});
+  out.push_back({"time_encoder.dense.weight", d * d});
+  out.push_back({"time_encoder.dense.bias", d});
+  out.push_back({"embedder.weight", d * C});
+  out.push_back({"embedder.bias", d});
+  out.push_back({"unembedder.weight", C * d});
+  out.push_back({"unembedder.bias", C});
+  for (int i = 0; i < m.num_layers; ++i) {
+    char p[64];
+    if (m.kind == FFD_MODEL_TRANSFORMER) {
+      snprintf(p, sizeof p, "backbone.layers.%d.", i);
+      std::string s(p);
+      out.push_back({s + "self_attn.in_proj_weight", 3 * d * d});
+      out.push_back({s + "self_attn.in_proj_bias", 3 * d});
+      out.push_back({s + "self_attn.out_proj.weight", d * d});
+      out.push_back({s + "self_attn.out_proj.bias", d});
+      out.push_back({s + "linear1.weight", F * d});
+      out.push_back({s + "linear1.bias", F});
+      out.push_back({s + "linear2.weight", d * F});
+      out.push_back({s + "linear2.bias", d});
+      out.push_back({s + "norm1.weight", d});
+      out.push_back({s + "norm1.bias", d});
+      out.push_back({s + "norm2.weight", d});
+      out.push_back({s + "norm2.bias", d});
+    } else {
+      snprintf(p, sizeof p, "backbone.%d.", i);
+      std::string s(p);
+      out.push_back({s + "weight_ih_l0", 4 * d * d});
+      out.push_back({s + "weight_hh_l0", 4 * d * d});
+      out.push_back({s + "bias_ih_l0", 4 * d});
+      out.push_back({s + "bias_hh_l0", 4 * d});
+    }
+  }
+}
+
+int ffd_load_weight(ffd_ctx* ctx, const char* name, const float* data, size_t n) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (!name || !data) return ctx->fail(FFD_ERR_INVALID, "ffd_load_weight: null argument");
+  std::vector<std::pair<std::string, size_t>> exp;
+  expected_weights(ctx->desc, exp);
+  size_t want = 0;
+  for (auto& kv : exp)
+    if (kv.first == name) want = kv.second;
+  if (!want) return ctx->fail(FFD_ERR_INVALID, "unexpected parameter '%s' for this model", name);
+  if (want != n) return ctx->fail(FFD_ERR_INVALID, "parameter '%s': got %zu floats, expected %zu", name, n, want);
+  HIPCHECK(hipSetDevice(ctx->device));
+  DevBuf& b = ctx->raw[name];
+  if (!b.p) {
+    hipError_t e = hipMalloc((void**)&b.p, n * sizeof(float) + 256);
+    if (e != hipSuccess) return ctx->fail(FFD_ERR_NOMEM, "hipMalloc for '%s' failed: %s", name, hipGetErrorString(e));
+    b.n = n;
+  }
+  HIPCHECK(hipMemcpy(b.p, data, n * sizeof(float), hipMemcpyDefault));
+  ctx->finalized = false;
+  return FFD_OK;
+}
+
+int ffd_finalize_weights(ffd_ctx* ctx) {
+  if (!ctx) return FFD_ERR_INVALID;
+  const ffd_model_desc& m = ctx->desc;
+  std::vector<std::pair<std::string, size_t>> exp;
+  expected_weights(m, exp);
+  for (auto& kv : exp)
+    if (!ctx->raw.count(kv.first)) return ctx->fail(FFD_ERR_STATE, "missing parameter '%s'", kv.first.c_str());
+  HIPCHECK(hipSetDevice(ctx->device));
+  const int d = m.d_model, F = m.dim_feedforward;
+  auto W = [&](const std::string& k) { return ctx->raw[k].p; };
+  hipStream_t s = nullptr;
+  if (m.kind == FFD_MODEL_TRANSFORMER) {
+    HIPCHECK(launch_renorm_rows(W("pos_encoder.embedding.weight"), m.max_len, d, sqrtf((float)d), s));
+    const bool first = ctx->packed.empty();
+    if (first) ctx->packed.resize(m.num_layers);
+    ctx->layers.resize(m.num_layers);
+    for (int i = 0; i < m.num_layers; ++i) {
+      char p[64];
+      snprintf(p, sizeof p, "backbone.layers.%d.", i);
+      std::string pre(p);
+      LayerPacked& pk = ctx->packed[i];
+      if (first) {
+        int rc;
+        if ((rc = dev_alloc(ctx, &pk.in_wp, dpack_floats(3 * d, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.q_wp, dpack_floats(d, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.kv_wp, dpack_floats(2 * d, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.out_wp, dpack_floats(d, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.w2p, w2pack_floats(d, F)))) return rc;
+      }
+      float* in_w = W(pre + "self_attn.in_proj_weight");
+      HIPCHECK(launch_pack_dweight(in_w, pk.in_wp, 3 * d, d, s));
+      HIPCHECK(launch_pack_dweight(in_w, pk.q_wp, d, d, s));
+      HIPCHECK(launch_pack_dweight(in_w + (size_t)d * d, pk.kv_wp, 2 * d, d, s));
+      HIPCHECK(launch_pack_dweight(W(pre + "self_attn.out_proj.weight"), pk.out_wp, d, d, s));
+      HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
+      HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
+      LayerWeights& lw = ctx->layers[i];
+      lw.in_w = in_w;
+      lw.in_b = W(pre + "self_attn.in_proj_bias");
+      lw.out_w = W(pre + "self_attn.out_proj.weight");
+      lw.out_b = W(pre + "self_attn.out_proj.bias");
+      lw.w1 = W(pre + "linear1.weight");
+      lw.b1 = W(pre + "linear1.bias");
+      lw.w2 = W(pre + "linear2.weight");
+      lw.b2 = W(pre + "linear2.bias");
+      lw.n1w = W(pre + "norm1.weight");
+      lw.n1b = W(pre + "norm1.bias");
+      lw.n2w = W(pre + "norm2.weight");
+      lw.n2b = W(pre + "norm2.bias");
+      lw.in_wp = pk.in_wp;
+      lw.out_wp = pk.out_wp;
+      lw.w1p = pk.w1p;
+      lw.w2p = pk.w2p;
+    }
+  } else {
+    const bool first = ctx->lstm.empty();
+    if (first) ctx->lstm.resize(m.num_layers);
+    for (int i = 0; i < m.num_layers; ++i) {
+      char p[64];
+      snprintf(p, sizeof p, "backbone.%d.", i);
+      std::string pre(p);
+      LstmLayer& l = ctx->lstm[i];
+      if (first) {
+        int rc;
+        if ((rc = dev_alloc(ctx, &l.wih_p, dpack_floats(4 * d, d)))) return rc;
+        if ((rc = dev_alloc(ctx, &l.bsum, 4 * d))) return rc;
+      }
+      l.wih = W(pre + "weight_ih_l0");
+      l.whh = W(pre + "weight_hh_l0");
+      l.bih = W(pre + "bias_ih_l0");
+      l.bhh = W(pre + "bias_hh_l0");
+      HIPCHECK(launch_pack_dweight(l.wih, l.wih_p, 4 * d, d, s));
+      hipLaunchKernelGGL(k_add_vec, dim3(cdiv(4 * d, 256)), dim3(256), 0, s, l.bih, l.bhh, l.bsum, 4 * d);
+      HIPCHECK(hipGetLastError());
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(s));
+  ctx->weight_epoch++;
+  ctx->finalized = true;
+  return FFD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------
+static int ensure_workspace(ffd_ctx* ctx, int B) {
+  if (B <= ctx->ws_B) return FFD_OK;
+  const ffd_model_desc& m = ctx->desc;
+  const size_t M = (size_t)B * m.max_len, d = m.d_model;
+  HIPCHECK(hipSetDevice(ctx->device));
+  // (old buffers stay owned until destroy; workspaces only grow a handful of times)
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->h0, M * d))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->score, M * m.n_channels))) return rc;
+  if (m.kind == FFD_MODEL_TRANSFORMER) {
+    if ((rc = dev_alloc(ctx, &ctx->h1, M * d))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->qkv, M * 3 * d))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->attn, M * d))) return rc;
+    if (!ctx->kvtmp && (rc = dev_alloc(ctx, &ctx->kvtmp, (size_t)m.max_len * 2 * d))) return rc;
+  } else {
+    if ((rc = dev_alloc(ctx, &ctx->qkv, M * 4 * d))) return rc;  // gate pre-activations gx
+  }
+  ctx->ws_B = B;
+  return FFD_OK;
+}
+
+// one score evaluation; temb points at d floats on the device.
+// n_rec < 0: no cache.  Otherwise the E2-CRF mode for |recompute_tokens| = n_rec.
+static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* score_out, float* crf_out, int B,
+                        int n_rec, hipStream_t s) {
+  const ffd_model_desc& m = ctx->desc;
+  const int L = m.max_len, C = m.n_channels, d = m.d_model, M = B * L;
+  if (m.kind == FFD_MODEL_LSTM) {
+    HIPCHECK(launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb, ctx->h0, B, L,
+                          C, d, s));
+    for (int i = 0; i < m.num_layers; ++i) {
+      const LstmLayer& l = ctx->lstm[i];
+      HIPCHECK(launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
+      HIPCHECK(launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
+    }
+    HIPCHECK(launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C,
+                            d, s));
+    return FFD_OK;
+  }
+  const int H = m.n_head, hd = d / H, F = m.dim_feedforward;
+  HIPCHECK(launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p,
+                        ctx->raw["pos_encoder.embedding.weight"].p, temb, ctx->h0, B, L, C, d, s));
+  // mode selection, cached_transformer.py:139-220
+  enum { STD, FULL, PURE, MIXED } mode = STD;
+  if (n_rec >= 0) {
+    if (n_rec == L) mode = FULL;
+    else if ((double)n_rec > 0.8 * (double)L) mode = STD;
+    else if (n_rec == 0) mode = PURE;
+    else mode = MIXED;
+  }
+  const size_t lt = (size_t)H * L * hd;  // table floats per layer
+  for (int i = 0; i < m.num_layers; ++i) {
+    const LayerWeights& w = ctx->layers[i];
+    const LayerPacked& pk = ctx->packed[i];
+    float* kt = ctx->kt ? ctx->kt + i * lt : nullptr;
+    float* vt = ctx->vt ? ctx->vt + i * lt : nullptr;
+    if (mode == PURE) {
+      HIPCHECK(launch_linear(ctx->h0, pk.q_wp, w.in_b, ctx->qkv, M, d, d, 3 * d, s));
+      HIPCHECK(launch_attention(ctx->qkv, kt, vt, ctx->attn, B, L, H, hd, 0, s));
+    } else if (mode == MIXED) {
+      HIPCHECK(launch_linear(ctx->h0, pk.in_wp, w.in_b, ctx->qkv, M, 3 * d, d, 3 * d, s));
+      HIPCHECK(launch_attention(ctx->qkv, kt, vt, ctx->attn, B, L, H, hd, n_rec, s));
+      // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
+      HIPCHECK(launch_kv_store(ctx->qkv + d, 3 * d, kt, vt, L, H, hd, n_rec, s));
+    } else {
+      HIPCHECK(launch_linear(ctx->h0, pk.in_wp, w.in_b, ctx->qkv, M, 3 * d, d, 3 * d, s));
+      HIPCHECK(launch_attention(ctx->qkv, nullptr, nullptr, ctx->attn, B, L, H, hd, L, s));
+    }
+    HIPCHECK(launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, ctx->h0, w.n1w, w.n1b, ctx->h1, M, d, s));
+    HIPCHECK(launch_ffn_ln(ctx->h1, w, ctx->h0, M, d, F, s));
+    if (mode == FULL) {
+      // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158)
+      HIPCHECK(launch_linear(ctx->h0, pk.kv_wp, w.in_b + d, ctx->kvtmp, L, 2 * d, d, 2 * d, s));
+      HIPCHECK(launch_kv_store(ctx->kvtmp, 2 * d, kt, vt, L, H, hd, L, s));
+    }
+    if (n_rec >= 0 && crf_out)  // crf[l] = h_l[0]  (score_models.py:181-194)
+      HIPCHECK(hipMemcpyAsync(crf_out + (size_t)i * L * d, ctx->h0, sizeof(float) * L * d, hipMemcpyDeviceToDevice, s));
+  }
+  if (n_rec >= 0) {  // counters, caching.py:283,299,396
+    if (mode == FULL) ctx->stats.recompute_count += (int64_t)L * m.num_layers, ctx->table_allocated = true;
+    else if (mode == PURE) ctx->stats.cache_hit_count += (int64_t)L * m.num_layers;
+    else if (mode == MIXED) {
+      ctx->stats.cache_hit_count += (int64_t)(L - n_rec) * m.num_layers;
+      ctx->stats.recompute_count += (int64_t)n_rec * m.num_layers;
+      ctx->table_allocated = true;
+    }
+  }
+  HIPCHECK(launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C, d,
+                          s));
+  return FFD_OK;
+}
+
+static int check_ready(ffd_ctx* ctx, int B) {
+  if (!ctx->finalized) return ctx->fail(FFD_ERR_STATE, "weights not finalised (call ffd_finalize_weights)");
+  if (B < 1) return ctx->fail(FFD_ERR_INVALID, "batch size %d", B);
+  if ((double)B * ctx->desc.max_len * 4 * ctx->desc.d_model > 2.0e9)
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "batch %d too large for 32-bit row indexing; shard the batch", B);
+  return FFD_OK;
+}
+
+static int temb_single(ffd_ctx* ctx, float t, hipStream_t s) {
+  HIPCHECK(launch_time_embed(nullptr, t, 1, ctx->raw["time_encoder.W"].p, ctx->raw["time_encoder.dense.weight"].p,
+                             ctx->raw["time_encoder.dense.bias"].p, ctx->temb1, ctx->desc.d_model, s));
+  return FFD_OK;
+}
+
+int ffd_score_forward(ffd_ctx* ctx, const float* x, float t, float* score_out, int B, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (!x || !score_out) return ctx->fail(FFD_ERR_INVALID, "null buffer");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = temb_single(ctx, t, s))) return rc;
+  return forward_impl(ctx, x, ctx->temb1, score_out, nullptr, B, -1, s);
+}
+
+int ffd_score_forward_cached(ffd_ctx* ctx, const float* x, float t, float* score_out, float* crf_out, int B,
+                             int n_recompute, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (ctx->desc.kind != FFD_MODEL_TRANSFORMER)
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "caching is only defined for the transformer backbone (SURVEY Q9)");
+  if (!ctx->cache_enabled) return ctx->fail(FFD_ERR_STATE, "cache not enabled (call ffd_cache_enable)");
+  if (!x || !score_out) return ctx->fail(FFD_ERR_INVALID, "null buffer");
+  if (n_recompute < 0 || n_recompute > ctx->desc.max_len)
+    return ctx->fail(FFD_ERR_INVALID, "n_recompute=%d outside [0,%d]", n_recompute, ctx->desc.max_len);
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if ((rc = temb_single(ctx, t, s))) return rc;
+  return forward_impl(ctx, x, ctx->temb1, score_out, crf_out, B, n_recompute, s);
+}
+
+// ---------------------------------------------------------------------------
+// SDE
+// ---------------------------------------------------------------------------
+static SdeParams sde_params(int sde, double a, double b, double t, float step_size) {
+  SdeParams p{};
+  p.sde = sde;
+  if (sde == FFD_SDE_VP) {
+    const double beta = a + t * (b - a);  // sde.py:212-213
+    p.a = (float)(-0.5 * beta);
+    p.cs = (float)sqrt(beta);
+  } else {
+    const double r = b / a;
+    p.cs = (float)(a * sqrt(2.0 * log(r)) * pow(r, t));  // sde.py:143-147
+    p.a = 0.f;
+  }
+  p.dt = step_size;
+  p.sqdt = sqrtf(step_size);
+  return p;
+}
+
+int ffd_sde_step(const ffd_sde_desc* sde, float* x, const float* score, const float* G, double t, float step_size,
+                 const float* z, uint64_t seed, uint64_t sample_offset, int step, int B, int L, int C, void* stream) {
+  if (!sde || !x || !score || !G || B < 1 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  if (sde->sde != FFD_SDE_VP && sde->sde != FFD_SDE_VE) return FFD_ERR_UNSUPPORTED;
+  if (!(step_size > 0.f)) return FFD_ERR_INVALID;  // sde.py:157,238 assert
+  hipError_t e = launch_sde_step(x, score, z, G, sde_params(sde->sde, sde->a, sde->b, t, step_size), seed,
+                                 sample_offset * (uint64_t)L * C, (uint32_t)step, B, L, C, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
+int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G, uint64_t seed, uint64_t sample_offset,
+              int B, int L, int C, void* stream) {
+  if (!sde || !x || !G || B < 1 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  const float scale = (sde->sde == FFD_SDE_VE) ? (float)sde->b : 1.0f;
+  hipError_t e = launch_prior(x, z, G, scale, seed, sample_offset * (uint64_t)L * C, B, L, C, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
+int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream) {
+  if (!in || !out || in == out || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  hipError_t e = launch_dft(in, out, B, L, C, 0, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream) {
+  if (!in || !out || in == out || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  hipError_t e = launch_dft(in, out, B, L, C, 1, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+// ---------------------------------------------------------------------------
+// cache lifecycle
+// ---------------------------------------------------------------------------
+int ffd_cache_enable(ffd_ctx* ctx, const ffd_cache_cfg* cfg) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (ctx->desc.kind != FFD_MODEL_TRANSFORMER)
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "caching is only defined for the transformer backbone (SURVEY Q9)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (cfg) ctx->ccfg = *cfg;
+  if (!ctx->kt) {
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->kt, ctx->table_floats()))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->vt, ctx->table_floats()))) return rc;
+  }
+  ctx->cache_enabled = true;
+  return ffd_cache_reset(ctx);
+}
+
+int ffd_cache_disable(ffd_ctx* ctx) {
+  if (!ctx) return FFD_ERR_INVALID;
+  ctx->cache_enabled = false;
+  return FFD_OK;
+}
+
+int ffd_cache_reset(ffd_ctx* ctx) {
+  if (!ctx) return FFD_ERR_INVALID;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (ctx->kt) {
+    // an unallocated reference table reads as zeros (cached_transformer.py:252-257)
+    HIPCHECK(hipMemset(ctx->kt, 0, ctx->table_floats() * sizeof(float)));
+    HIPCHECK(hipMemset(ctx->vt, 0, ctx->table_floats() * sizeof(float)));
+  }
+  ctx->table_allocated = false;
+  ctx->stats = ffd_cache_stats{};
+  return FFD_OK;
+}
+
+int ffd_cache_stats_get(const ffd_ctx* ctx, ffd_cache_stats* out) {
+  if (!ctx || !out) return FFD_ERR_INVALID;
+  *out = ctx->stats;
+  out->table_allocated = ctx->table_allocated ? 1 : 0;
+  return FFD_OK;
+}
+
+int ffd_cache_tables_read(ffd_ctx* ctx, float* k_out, float* v_out, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (!k_out || !v_out) return ctx->fail(FFD_ERR_INVALID, "null buffer");
+  if (!ctx->kt) return ctx->fail(FFD_ERR_STATE, "cache not enabled (call ffd_cache_enable)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  const size_t bytes = ctx->table_floats() * sizeof(float);
+  HIPCHECK(hipMemcpyAsync(k_out, ctx->kt, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIPCHECK(hipMemcpyAsync(v_out, ctx->vt, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return FFD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// the sampling loop (sampler.py:156-210)
+// ---------------------------------------------------------------------------
+int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int n_steps, float step_size,
+                     int first_step, int n_run, uint64_t seed, uint64_t sample_offset, const float* z_inject,
+                     int use_cache, int global_step0, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (!x || !timesteps || n_steps < 1 || first_step < 0 || n_run < 0 || first_step + n_run > n_steps)
+    return ctx->fail(FFD_ERR_INVALID, "bad argument to ffd_sample_batch (n_steps=%d first=%d run=%d)", n_steps,
+                     first_step, n_run);
+  if (!(step_size > 0.f)) return ctx->fail(FFD_ERR_INVALID, "step_size must be > 0 (sde.py:157,238)");
+  if (use_cache && !ctx->cache_enabled) return ctx->fail(FFD_ERR_STATE, "use_cache without ffd_cache_enable");
+  if (use_cache && ctx->desc.kind != FFD_MODEL_TRANSFORMER)
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "caching is only defined for the transformer backbone");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  const ffd_model_desc& m = ctx->desc;
+  const int d = m.d_model;
+  hipStream_t s = (hipStream_t)stream;
+  // All time embeddings of the trajectory in one launch: t is shared by the batch
+  // (sampler.py:59-60).  The table is kept across batches and only rebuilt (with one
+  // stream sync) when the timestep grid or the weights changed.
+  if ((int)ctx->ts_host.size() != n_steps || memcmp(ctx->ts_host.data(), timesteps, sizeof(float) * n_steps) != 0 ||
+      ctx->temb_epoch != ctx->weight_epoch) {
+    HIPCHECK(hipStreamSynchronize(s));
+    if (n_steps > ctx->temb_cap) {
+      if ((rc = dev_alloc(ctx, &ctx->temb_tab, (size_t)n_steps * d))) return rc;
+      if ((rc = dev_alloc(ctx, &ctx->ts_dev, (size_t)n_steps))) return rc;
+      ctx->temb_cap = n_steps;
+    }
+    ctx->ts_host.assign(timesteps, timesteps + n_steps);
+    HIPCHECK(hipMemcpy(ctx->ts_dev, ctx->ts_host.data(), sizeof(float) * n_steps, hipMemcpyHostToDevice));
+    HIPCHECK(launch_time_embed(ctx->ts_dev, 0.f, n_steps, ctx->raw["time_encoder.W"].p,
+                               ctx->raw["time_encoder.dense.weight"].p, ctx->raw["time_encoder.dense.bias"].p,
+                               ctx->temb_tab, d, s));
+    ctx->temb_epoch = ctx->weight_epoch;
+  }
+  const size_t slab = (size_t)B * m.max_len * m.n_channels;
+  const uint64_t elem_off = sample_offset * (uint64_t)m.max_len * m.n_channels;
+  for (int j = 0; j < n_run; ++j) {
+    const int i = first_step + j;
+    int n_rec = -1;
+    if (use_cache) {
+      const int gstep = global_step0 + j;
+      ctx->stats.current_step = gstep;
+      n_rec = ffd_host_gate(gstep, m.max_len, ctx->ccfg.K, ctx->ccfg.R);
+    }
+    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, ctx->score, nullptr, B, n_rec, s))) return rc;
+    if (use_cache) ctx->stats.current_step = i;  // sampler.py:73-74 (Q4)
+    const double t = (double)timesteps[i];
+    HIPCHECK(launch_sde_step(x, ctx->score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
+                             sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B, m.max_len,
+                             m.n_channels, s));
+  }
+  return FFD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// benchmark introspection
+// ---------------------------------------------------------------------------
+double ffd_flops_per_sample_step(const ffd_ctx* ctx, int cache_hit) {
+  if (!ctx) return 0.0;
+  const ffd_model_desc& m = ctx->desc;
+  const double L = m.max_len, d = m.d_model, C = m.n_channels, NL = m.num_layers, F = m.dim_feedforward;
+  if (m.kind == FFD_MODEL_LSTM) return NL * 2.0 * L * (2.0 * 4.0 * d * d) + 4.0 * L * C * d + 2.0 * d * d;
+  double per_layer = 2.0 * L * d * 3.0 * d + 2.0 * L * L * d + 2.0 * L * L * d + 2.0 * L * d * d + 4.0 * L * d * F;
+  if (cache_hit) per_layer -= 2.0 * L * d * 2.0 * d;
+  return NL * per_layer + 4.0 * L * C * d + 2.0 * d * d;
+}
+
+double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B) {
+  if (!ctx) return 0.0;
+  const ffd_model_desc& m = ctx->desc;
+  return 4.0 * (double)B * m.max_len * m.d_model * m.dim_feedforward;
+}
+
+int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (ctx->desc.kind != FFD_MODEL_TRANSFORMER) return ctx->fail(FFD_ERR_UNSUPPORTED, "no FFN in the LSTM backbone");
+  if (iters < 1 || !ms_out) return ctx->fail(FFD_ERR_INVALID, "bad argument to ffd_bench_ffn");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  const ffd_model_desc& m = ctx->desc;
+  const int M = B * m.max_len, d = m.d_model;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);
+  HIPCHECK(hipGetLastError());
+  for (int i = 0; i < 3; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  HIPCHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+  HIPCHECK(hipEventRecord(e1, s));
+  HIPCHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_out = ms / iters;
+  return FFD_OK;
+}
+
+}  // extern "C"

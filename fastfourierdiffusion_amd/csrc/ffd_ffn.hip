@@ -1,0 +1,207 @@
+// Fused feed-forward block of the post-norm encoder layer (cached_transformer.py:325-327,
+// nn.TransformerEncoderLayer._ff_block):
+//     Y = LayerNorm2( X + W2 relu(W1 X + b1) + b2 )
+// >= 86 % of the FLOPs of a score evaluation.  MFMA-bound (exact fp32
+// v_mfma_f32_16x16x4_f32, 157 TFLOP/s peak); the (rows x F) hidden never leaves
+// registers:
+//
+//   GEMM1  H^T[f][m] = sum_k W1[f][k] X[m][k]      A = W1 fragment, B = X fragment
+//   relu(H + b1) stays in the accumulator registers, whose layout
+//       lane l, reg r  <->  H^T[f = 4 (l>>4) + r][m = l & 15]
+//   is exactly the B-operand layout (k = l>>4, j = l&15) of the next MFMA when the
+//   A operand is pre-packed as W2[c = l&15][f = 4 (l>>4) + r]  ("w2pack"), so
+//   GEMM2  Y^T[c][m] += sum_f W2[c][f] H^T[f][m]   needs no LDS and no lane movement.
+//
+// Work split: one workgroup = 16*MB rows; its 4 waves (one per SIMD) split F four
+// ways, each keeping the X fragments (MB*D/4 VGPRs) and a private Y^T accumulator
+// (MB*ceil(D/16)*4 VGPRs) resident and streaming only packed weights from L2
+// (2 coalesced float4 per lane per 16-wide F chunk).  Partial Y^T tiles are summed
+// in wave order through the LDS copy of the X tile (deterministic), which also
+// provides the residual; LayerNorm2 runs on that tile and rows are written back
+// fully coalesced.
+#include "ffd_internal.h"
+
+namespace ffd {
+
+template <int D, int MB>
+__global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, const float* __restrict__ W1p,
+                                                  const float* __restrict__ b1, const float* __restrict__ W2p,
+                                                  const float* __restrict__ b2, const float* __restrict__ gam,
+                                                  const float* __restrict__ bet, float* __restrict__ Y, int M,
+                                                  int F) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  constexpr int CT = cdiv(D, 16);
+  constexpr int R = 16 * MB;
+  __shared__ float xs[R * S];
+
+  const int m0 = blockIdx.x * R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- stage the X tile (coalesced) and pull this wave's B fragments ----
+  for (int idx = threadIdx.x; idx < R * D; idx += 256) {
+    int r = idx / D, k = idx - r * D;
+    int m = m0 + r;
+    xs[r * S + k] = (m < M) ? X[(size_t)m * D + k] : 0.f;
+  }
+  __syncthreads();
+  float xf[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
+
+  f32x4 yacc[CT][MB];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- main loop over this wave's quarter of F, 16 hidden units per chunk ----
+  const int nchunk = F / 64;  // chunks per wave
+  const int fc0 = wave * nchunk;
+  const float4* W1q = reinterpret_cast<const float4*>(W1p) + (size_t)fc0 * G * 64 + lane;
+  const float4* W2q = reinterpret_cast<const float4*>(W2p) + (size_t)fc0 * CT * 64 + lane;
+  const float4* b1q = reinterpret_cast<const float4*>(b1 + 16 * fc0) + (lane >> 4);
+
+  float4 w1n[G], w2n[CT], bn;
+#pragma unroll
+  for (int g = 0; g < G; ++g) w1n[g] = W1q[g * 64];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) w2n[ct] = W2q[ct * 64];
+  bn = b1q[0];
+
+  for (int ci = 0; ci < nchunk; ++ci) {
+    float4 w1c[G], w2c[CT], bc = bn;
+#pragma unroll
+    for (int g = 0; g < G; ++g) w1c[g] = w1n[g];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) w2c[ct] = w2n[ct];
+    // prefetch the next chunk's fragments (clamped on the last iteration)
+    const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;
+#pragma unroll
+    for (int g = 0; g < G; ++g) w1n[g] = W1q[((size_t)nx * G + g) * 64];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) w2n[ct] = W2q[((size_t)nx * CT + ct) * 64];
+    bn = b1q[nx * 4];
+
+    // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D
+    f32x4 h[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{bc.x, bc.y, bc.z, bc.w};  // bias as the initial accumulator
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 q = w1c[s >> 2];
+      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) h[mb] = mfma16(a, xf[mb][s], h[mb]);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
+
+    // GEMM2: Y^T += W2[:, chunk] H^T chunk ; accumulator register r is the k-step
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float4 q = w2c[ct];
+        const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
+      }
+  }
+
+  // ---- deterministic cross-wave reduction through the LDS X tile ----
+  // xs holds X (the residual); wave w adds its partial after waves < w.
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * (lane >> 4) + r;
+            if (c < D) xs[(16 * mb + (lane & 15)) * S + c] += yacc[ct][mb][r];
+          }
+    }
+  }
+  __syncthreads();
+
+  // ---- + b2, LayerNorm2, coalesced store ----
+  constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
+  const int row = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+  const int m = m0 + row;
+  float vals[cdiv(D, TPR)];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < cdiv(D, TPR); ++i) {
+    const int c = sub + i * TPR;
+    float v = 0.f;
+    if (c < D) {
+      v = xs[row * S + c] + b2[c];
+      sum += v;
+    }
+    vals[i] = v;
+  }
+#pragma unroll
+  for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < cdiv(D, TPR); ++i) {
+    const int c = sub + i * TPR;
+    if (c < D) {
+      float dlt = vals[i] - mean;
+      ss = fmaf(dlt, dlt, ss);
+    }
+  }
+#pragma unroll
+  for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+  if (m < M) {
+#pragma unroll
+    for (int i = 0; i < cdiv(D, TPR); ++i) {
+      const int c = sub + i * TPR;
+      if (c < D) Y[(size_t)m * D + c] = (vals[i] - mean) * rstd * gam[c] + bet[c];
+    }
+  }
+}
+
+template <int D>
+static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s) {
+  // Tile height: the largest 16*MB rows that still yields >= ~2 workgroups per CU.
+  const int target = 2 * 256;
+  dim3 block(256);
+  if (cdiv(M, 128) >= target) {
+    hipLaunchKernelGGL((k_ffn_ln<D, 8>), dim3(cdiv(M, 128)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
+                       Y, M, F);
+  } else if (cdiv(M, 64) >= target) {
+    hipLaunchKernelGGL((k_ffn_ln<D, 4>), dim3(cdiv(M, 64)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
+                       Y, M, F);
+  } else if (cdiv(M, 32) >= target) {
+    hipLaunchKernelGGL((k_ffn_ln<D, 2>), dim3(cdiv(M, 32)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
+                       Y, M, F);
+  } else {
+    hipLaunchKernelGGL((k_ffn_ln<D, 1>), dim3(cdiv(M, 16)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
+                       Y, M, F);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  if (F % 64 != 0) return hipErrorInvalidValue;
+  switch (D) {
+    case 24: return launch_ffn_d<24>(X, w, Y, M, F, s);
+    case 60: return launch_ffn_d<60>(X, w, Y, M, F, s);
+    case 72: return launch_ffn_d<72>(X, w, Y, M, F, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ffd

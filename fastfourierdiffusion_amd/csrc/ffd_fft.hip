@@ -1,0 +1,194 @@
+// Packed ortho real FFT / inverse along dim 1 of (B, L, C)  (fourier.py:8-94).
+//
+// One workgroup owns one sample's (L x CG) slab: a single coalesced HBM read into
+// LDS, every Stockham autosort pass ping-pongs between two LDS buffers, a single
+// coalesced HBM write of the packed spectrum -- 8 B of HBM traffic per element.
+// Any length: L is factored into radices (8/4/2 for powers of two, odd primes as
+// they come, e.g. 187 = 11 * 17, 251 = 251) and each pass evaluates its radix-R
+// butterflies output-by-output straight from one length-L twiddle table
+//     w_R^{jk} = W_L[(jk mod R) L/R]      w_n^{pk} = W_L[p k s]      (n s = L)
+// computed on the host in double precision.
+//
+// Packed layout (fourier.py:24-47): out[0 .. L/2] = Re X_k, out[L/2+1 ..] = Im X_k for
+// k = 1 .. ceil(L/2)-1; scale 1/sqrt(L) both ways.
+#include <math.h>
+
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "ffd_internal.h"
+
+namespace ffd {
+
+struct FftPlan {
+  int npass;
+  int radix[16];
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float* __restrict__ out,
+                                             const float2* __restrict__ Wg, FftPlan plan, int L, int C, int CG,
+                                             float scale) {
+  extern __shared__ __align__(16) float2 sm[];
+  float2* W = sm;               // L twiddles
+  float2* bufA = sm + L;        // L * CG
+  float2* bufB = bufA + L * CG;
+  const int b = blockIdx.x;
+  const int c0 = blockIdx.y * CG;
+  const int cg = min(CG, C - c0);
+  const float* src = in + (size_t)b * L * C;
+  float* dst = out + (size_t)b * L * C;
+  const int n_re = L / 2 + 1;
+
+  for (int i = threadIdx.x; i < L; i += blockDim.x) {
+    float2 w = Wg[i];
+    if (INVERSE) w.y = -w.y;
+    W[i] = w;
+  }
+  if (!INVERSE) {
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      int l = idx / cg, cc = idx - l * cg;
+      bufA[l * CG + cc] = make_float2(src[(size_t)l * C + c0 + cc], 0.f);
+    }
+  } else {
+    // rebuild the Hermitian spectrum X[k], k = 0..L-1 from the packed layout
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      int k = idx / cg, cc = idx - k * cg;
+      int kk = (k < n_re) ? k : L - k;  // source harmonic
+      float re = src[(size_t)kk * C + c0 + cc];
+      float im = 0.f;
+      if (kk >= 1 && kk <= L - n_re) im = src[(size_t)(n_re + kk - 1) * C + c0 + cc];
+      if (k >= n_re) im = -im;
+      bufA[k * CG + cc] = make_float2(re, im);
+    }
+  }
+  __syncthreads();
+
+  float2* x = bufA;
+  float2* y = bufB;
+  int n = L, s = 1;
+  for (int ps = 0; ps < plan.npass; ++ps) {
+    const int R = plan.radix[ps];
+    const int m = n / R;
+    const int LR = L / R;
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      const int i = idx / cg, cc = idx - i * cg;
+      const int q = i % s;
+      const int t = i / s;
+      const int k = t % R;
+      const int p = t / R;
+      const float2* xp = x + (size_t)(q + s * p) * CG + cc;
+      const int stride = s * m * CG;
+      float2 acc = xp[0];
+      int tw = 0;  // (j*k mod R) * L/R
+      for (int j = 1; j < R; ++j) {
+        tw += k * LR;
+        if (tw >= L) tw -= L;
+        float2 a = xp[(size_t)j * stride];
+        float2 w = W[tw];
+        acc.x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc.x));
+        acc.y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc.y));
+      }
+      acc = cmul(acc, W[p * k * s]);
+      y[(size_t)i * CG + cc] = acc;
+    }
+    __syncthreads();
+    float2* tmp = x;
+    x = y;
+    y = tmp;
+    n = m;
+    s *= R;
+  }
+
+  if (!INVERSE) {
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      int o = idx / cg, cc = idx - o * cg;
+      float v;
+      if (o < n_re) v = x[o * CG + cc].x;
+      else v = x[(o - n_re + 1) * CG + cc].y;
+      dst[(size_t)o * C + c0 + cc] = v * scale;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      int o = idx / cg, cc = idx - o * cg;
+      dst[(size_t)o * C + c0 + cc] = x[o * CG + cc].x * scale;
+    }
+  }
+}
+
+static FftPlan make_plan(int L) {
+  FftPlan p{};
+  int n = L;
+  auto push = [&](int r) { p.radix[p.npass++] = r; };
+  while (n % 8 == 0) push(8), n /= 8;
+  while (n % 4 == 0) push(4), n /= 4;
+  while (n % 2 == 0) push(2), n /= 2;
+  for (int f = 3; (long)f * f <= n; f += 2)
+    while (n % f == 0) push(f), n /= f;
+  if (n > 1) push(n);
+  if (L == 1) push(1);
+  return p;
+}
+
+namespace {
+std::mutex g_tw_mutex;
+std::map<std::pair<int, int>, float2*> g_twiddles;  // (device, L) -> device table
+}  // namespace
+
+static hipError_t get_twiddles(int L, const float2** out) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  auto key = std::make_pair(dev, L);
+  auto it = g_twiddles.find(key);
+  if (it != g_twiddles.end()) {
+    *out = it->second;
+    return hipSuccess;
+  }
+  std::vector<float2> h(L);
+  for (int i = 0; i < L; ++i) {
+    double a = -2.0 * M_PI * (double)i / (double)L;
+    h[i] = make_float2((float)cos(a), (float)sin(a));
+  }
+  float2* d = nullptr;
+  e = hipMalloc(&d, sizeof(float2) * L);
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(d, h.data(), sizeof(float2) * L, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(d);
+    return e;
+  }
+  g_twiddles[key] = d;
+  *out = d;
+  return hipSuccess;
+}
+
+hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (L < 1 || C < 1 || L > 8192) return hipErrorInvalidValue;
+  const float2* W = nullptr;
+  hipError_t e = get_twiddles(L, &W);
+  if (e != hipSuccess) return e;
+  FftPlan plan = make_plan(L);
+  if (plan.npass > 16) return hipErrorInvalidValue;
+  // channels per workgroup so that twiddles + two slabs fit in 64 KiB of LDS
+  int CG = C;
+  while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
+  size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  dim3 grid(B, cdiv(C, CG)), block(256);
+  float scale = (float)(1.0 / sqrt((double)L));
+  if (inverse)
+    hipLaunchKernelGGL(k_fft<true>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
+  else
+    hipLaunchKernelGGL(k_fft<false>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
+  return hipGetLastError();
+}
+
+}  // namespace ffd

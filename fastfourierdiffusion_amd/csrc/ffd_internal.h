@@ -1,0 +1,100 @@
+// Internal declarations shared by the libffd translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ffd {
+
+constexpr int WAVE = 64;
+
+// ---- MFMA f32 16x16x4 fragment conventions (cdna_hip_programming.md §3) ----
+//   A operand: lane l holds A[i = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][j = l & 15]
+//   C/D      : lane l, reg r holds D[i = 4 * (l >> 4) + r][j = l & 15]
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+constexpr __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Padded LDS row stride (in floats) for a (rows x D) fp32 tile whose MFMA
+// fragments are read with ds_read_b32 as tile[(l&15)*stride + 4s + (l>>4)]:
+// stride/2 odd => the 16 rows x 2 k of each 32-lane half hit 32 distinct banks.
+constexpr __host__ __device__ int lds_stride(int D) { return D + ((6 - D % 4) % 4); }
+
+// ---- packed weight layouts -------------------------------------------------
+// "dpack": a (N x D) weight (PyTorch (out,in) order) packed as the A operand of
+// Y^T = W X^T :  [nt = N/16 tiles][g = ceil(ceil(D/4)/4)][lane 64][j 4]
+//   = W[16 nt + (lane & 15)][4 (4 g + j) + (lane >> 4)]   (0 outside N x D)
+// so that one coalesced float4 load per lane yields 4 consecutive k-steps.
+constexpr __host__ __device__ int dpack_groups(int D) { return cdiv(cdiv(D, 4), 4); }
+constexpr __host__ __device__ size_t dpack_floats(int N, int D) {
+  return (size_t)cdiv(N, 16) * dpack_groups(D) * 64 * 4;
+}
+// "w2pack": linear2.weight (D x F) packed as the A operand of Y^T += W2 H^T with
+// the GEMM1 accumulator as B:  [fc = F/16][ct = ceil(D/16)][lane 64][r 4]
+//   = W2[16 ct + (lane & 15)][16 fc + 4 (lane >> 4) + r]      (0 for c >= D)
+constexpr __host__ __device__ size_t w2pack_floats(int D, int F) { return (size_t)(F / 16) * cdiv(D, 16) * 64 * 4; }
+
+// ---- launchers (each returns the hipError_t of the launch) -----------------
+
+struct LayerWeights {
+  // raw (device) parameters
+  const float *in_w, *in_b, *out_w, *out_b, *w1, *b1, *w2, *b2, *n1w, *n1b, *n2w, *n2b;
+  // packed
+  const float *in_wp;   // dpack (3d x d)
+  const float *out_wp;  // dpack (d x d)
+  const float *w1p;     // dpack (F x d)
+  const float *w2p;     // w2pack
+};
+
+hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s);
+hipError_t launch_pack_w2(const float* W2, float* W2p, int D, int F, hipStream_t s);
+hipError_t launch_renorm_rows(float* W, int rows, int D, float max_norm, hipStream_t s);
+
+// temb[n][d] = dense(gamma(t_n)) for n timesteps (transformer.py:77-91)
+// (ts == nullptr: a single embedding of the immediate t_imm)
+hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W, const float* dense_w,
+                             const float* dense_b, float* temb, int D, hipStream_t s);
+// h[b,l,:] = X[b,l,:] We^T + be (+ pos[l,:]) + temb[:]
+hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
+                        float* h, int B, int L, int C, int D, hipStream_t s);
+// score[b,l,c] = h[b,l,:] . Wu[c,:] + bu[c]
+hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, float* score, int M, int C, int D,
+                          hipStream_t s);
+
+struct SdeParams {
+  int sde;          // 0 VP 1 VE
+  float a;          // VP: (float)(-0.5*beta)        VE: unused
+  float cs;         // (float)sqrt(beta) | (float)sqrt_derivative
+  float dt, sqdt;   // step_size, sqrtf(step_size)
+};
+hipError_t launch_sde_step(float* x, const float* score, const float* z, const float* G, SdeParams p, uint64_t seed,
+                           uint64_t elem_offset, uint32_t step, int B, int L, int C, hipStream_t s);
+hipError_t launch_prior(float* x, const float* z, const float* G, float scale, uint64_t seed, uint64_t elem_offset,
+                        int B, int L, int C, hipStream_t s);
+
+// Y[M x N] (row stride ldy) = X[M x D] Wp^T + b ; Wp is dpack of the N x D weight.
+hipError_t launch_linear(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int D, int ldy,
+                         hipStream_t s);
+// Y[M x D] = LayerNorm(R + X Wp^T + b) * g + beta    (out-proj + residual + LN1)
+hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bias, const float* R, const float* g,
+                                const float* beta, float* Y, int M, int D, hipStream_t s);
+// Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
+hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s);
+
+// attention over qkv (M x 3d row-major, [q|k|v]); tokens >= n_own take K/V from the
+// (H,L,hd) tables kt/vt instead of the sample's own rows. out: (M x d).
+hipError_t launch_attention(const float* qkv, const float* kt, const float* vt, float* out, int B, int L, int H,
+                            int hd, int n_own, hipStream_t s);
+// table[h][l][e] (l < n) <- kv[l][which*d + h*hd + e]  from a (L x 2d) [k|v] buffer of sample 0
+hipError_t launch_kv_store(const float* kv, int ldkv, float* kt, float* vt, int L, int H, int hd, int n, hipStream_t s);
+// crf[l][:] <- h[l][:] for sample 0 is a plain D2D copy (done with hipMemcpyAsync)
+
+hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
+
+hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s);
+
+}  // namespace ffd

@@ -1,0 +1,184 @@
+// d-contraction GEMMs on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32):
+//   Y^T[n][m] = sum_k W[n][k] X[m][k]     (A = packed W fragment, B = X fragment)
+// K is always d_model (<= 80) on this path, so the X fragments of a 64-row tile live
+// in registers for the whole kernel and only packed weights stream (L2-resident,
+// one coalesced float4 per lane = 4 k-steps).
+//   k_linear         : Y = X W^T + b                       (QKV / KV / LSTM gates)
+//   k_linear_res_ln  : Y = LN(R + X W^T + b)               (out-proj + residual + LN1)
+#include "ffd_internal.h"
+
+namespace ffd {
+
+template <int D>
+__device__ __forceinline__ void load_x_tile(const float* __restrict__ X, float* xs, int m0, int M) {
+  constexpr int S = lds_stride(D);
+  for (int idx = threadIdx.x; idx < 64 * D; idx += blockDim.x) {
+    int r = idx / D, k = idx - r * D;
+    int m = m0 + r;
+    xs[r * S + k] = (m < M) ? X[(size_t)m * D + k] : 0.f;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                const float* __restrict__ bias, float* __restrict__ Y, int M, int N,
+                                                int ldy) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  __shared__ float xs[64 * S];
+  const int m0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_x_tile<D>(X, xs, m0, M);
+  __syncthreads();
+  float xf[4][KS];
+#pragma unroll
+  for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
+
+  const int NT = cdiv(N, 16);
+  const float4* Wq = reinterpret_cast<const float4*>(Wp);
+  const bool vec_ok = ((ldy & 3) == 0) && ((N & 3) == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15) == 0);
+  for (int nt = wave; nt < NT; nt += 4) {
+    float4 wq[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = Wq[((size_t)nt * G + g) * 64 + lane];
+    f32x4 acc[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 q = wq[s >> 2];
+      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb) acc[mb] = mfma16(a, xf[mb][s], acc[mb]);
+    }
+    const int n = 16 * nt + 4 * (lane >> 4);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+      const int m = m0 + 16 * mb + (lane & 15);
+      if (m >= M) continue;
+      float* yr = Y + (size_t)m * ldy + n;
+      if (vec_ok && n + 3 < N) {
+        float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+        float4 o = {acc[mb][0] + b4.x, acc[mb][1] + b4.y, acc[mb][2] + b4.z, acc[mb][3] + b4.w};
+        *reinterpret_cast<float4*>(yr) = o;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) yr[r] = acc[mb][r] + bias[n + r];
+      }
+    }
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                                       const float* __restrict__ gam, const float* __restrict__ bet,
+                                                       float* __restrict__ Y, int M) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  constexpr int CT = cdiv(D, 16);
+  __shared__ float xs[64 * S];
+  const int m0 = blockIdx.x * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_x_tile<D>(X, xs, m0, M);
+  __syncthreads();
+  float xf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) xf[s] = xs[(16 * wave + (lane & 15)) * S + 4 * s + (lane >> 4)];
+
+  const float4* Wq = reinterpret_cast<const float4*>(Wp);
+  f32x4 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float4 wq[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = Wq[((size_t)ct * G + g) * 64 + lane];
+    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 q = wq[s >> 2];
+      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+      acc[ct] = mfma16(a, xf[s], acc[ct]);
+    }
+  }
+  // epilogue: lane holds row m, columns n = 16 ct + 4 (lane>>4) + r
+  const int m = m0 + 16 * wave + (lane & 15);
+  const int mc = m < M ? m : M - 1;
+  float v[CT][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 16 * ct + 4 * (lane >> 4) + r;
+      if (n < D) {
+        v[ct][r] = acc[ct][r] + bias[n] + R[(size_t)mc * D + n];
+        sum += v[ct][r];
+      } else {
+        v[ct][r] = 0.f;
+      }
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = 16 * ct + 4 * (lane >> 4) + r;
+      if (n < D) {
+        float dlt = v[ct][r] - mean;
+        ss = fmaf(dlt, dlt, ss);
+      }
+    }
+  ss += __shfl_xor(ss, 16);
+  ss += __shfl_xor(ss, 32);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+  if (m < M) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = 16 * ct + 4 * (lane >> 4);
+      if (n + 3 < D) {
+        float4 g4 = *reinterpret_cast<const float4*>(gam + n);
+        float4 b4 = *reinterpret_cast<const float4*>(bet + n);
+        float4 o = {(v[ct][0] - mean) * rstd * g4.x + b4.x, (v[ct][1] - mean) * rstd * g4.y + b4.y,
+                    (v[ct][2] - mean) * rstd * g4.z + b4.z, (v[ct][3] - mean) * rstd * g4.w + b4.w};
+        *reinterpret_cast<float4*>(Y + (size_t)m * D + n) = o;
+      }
+    }
+  }
+}
+
+hipError_t launch_linear(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int D, int ldy,
+                         hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  dim3 grid(cdiv(M, 64)), block(256);
+  switch (D) {
+    case 24: hipLaunchKernelGGL(k_linear<24>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+    case 60: hipLaunchKernelGGL(k_linear<60>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+    case 72: hipLaunchKernelGGL(k_linear<72>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bias, const float* R, const float* g,
+                                const float* beta, float* Y, int M, int D, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  dim3 grid(cdiv(M, 64)), block(256);
+  switch (D) {
+    case 24: hipLaunchKernelGGL(k_linear_res_ln<24>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
+    case 60: hipLaunchKernelGGL(k_linear_res_ln<60>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
+    case 72: hipLaunchKernelGGL(k_linear_res_ln<72>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace ffd

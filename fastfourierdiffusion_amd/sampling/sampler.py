@@ -1,0 +1,184 @@
+"""``fdiff.sampling.sampler`` mirror: ``DiffusionSampler``
+(reference src/fdiff/sampling/sampler.py:14-228).
+
+Same constructor, attributes and ``sample`` / ``reverse_diffusion_step`` /
+``sample_prior`` contracts.  ``sample`` keeps the reference's batching rules (remainder
+samples dropped, Q10), cache lifecycle (reset only for batch 0, global step keeps
+counting, Q3) and returns a CPU tensor, but runs each batch's whole reverse-diffusion
+loop through ``ffd_sample_batch``: every kernel of every step is enqueued on the
+current HIP stream with no host synchronisation (the reference syncs several times per
+step: ``.item()``, ``min == max`` assert, H2D ``diag_embed`` copies).
+
+Noise: ``rng="torch"`` (default) draws z exactly where the reference does --
+``torch.randn`` on the CPU generator for the prior, ``torch.randn_like`` on the device
+generator for every step -- so a seeded run matches the reference run on the same
+device.  ``rng="philox"`` generates the draws inside the step kernel (Philox4x32-10
+keyed by (seed, step, global element index)): no z traffic, and results are invariant
+to how samples are sharded over GPUs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Literal, Optional
+
+import torch
+
+from .. import _native as N
+from ..models.score_models import ScoreModule
+from ..schedulers.sde import SDE
+from ..utils.dataclasses import DiffusableBatch
+
+
+class DiffusionSampler:
+    def __init__(self, score_model: ScoreModule, sample_batch_size: int, use_cache: bool = False,
+                 cache_kwargs: Optional[dict] = None, use_fresca: bool = False, fresca_low_scale: float = 1.0,
+                 fresca_high_scale: float = 1.5, fresca_cutoff_ratio: float = 0.5,
+                 fresca_cutoff_strategy: Literal["spatial", "energy"] = "energy",
+                 rng: Literal["torch", "philox"] = "torch", seed: int = 42, sample_offset: int = 0,
+                 z_chunk_steps: int = 50) -> None:
+        self.score_model = score_model
+        self.noise_scheduler = score_model.noise_scheduler
+        self.sample_batch_size = sample_batch_size
+        self.n_channels = score_model.n_channels
+        self.max_len = score_model.max_len
+
+        self.use_cache = use_cache
+        if use_cache:
+            cache_kwargs = cache_kwargs or {}
+            self.score_model.enable_caching(**cache_kwargs)  # sampler.py:37-39
+
+        self.use_fresca = use_fresca
+        self.fresca_low_scale = fresca_low_scale
+        self.fresca_high_scale = fresca_high_scale
+        self.fresca_cutoff_ratio = fresca_cutoff_ratio
+        self.fresca_cutoff_strategy = fresca_cutoff_strategy
+        if use_fresca:
+            raise NotImplementedError(
+                "use_fresca=True: FreSca per-step spectral scaling is the first 'next' row of the scope table "
+                "(SURVEY 8(f)); not built yet")
+        # extensions (not in the reference signature)
+        assert rng in ("torch", "philox")
+        self.rng = rng
+        self.seed = int(seed)
+        self.sample_offset = int(sample_offset)
+        self.z_chunk_steps = int(z_chunk_steps)
+        self._injected = None
+
+    def inject_noise(self, draws) -> None:
+        """Parity hook: take every N(0,1) draw (one (B,L,C) array for each batch's prior,
+        then one per step) from the iterable ``draws`` instead of torch's generators --
+        the product-side twin of the noise patching in oracle/gen_golden.py."""
+        self._injected = iter(draws) if draws is not None else None
+
+    def _next_injected(self, shape, device) -> torch.Tensor:
+        z = next(self._injected)
+        z = torch.as_tensor(z, dtype=torch.float32)
+        assert tuple(z.shape) == tuple(shape), (tuple(z.shape), tuple(shape))
+        return z.to(device)
+
+    # ------------------------------------------------------------------
+    def reverse_diffusion_step(self, batch: DiffusableBatch, step: int = 0,
+                               recompute_tokens: Optional[set] = None) -> torch.Tensor:
+        """sampler.py:48-103 (single-step API; ``sample`` uses the fused loop)."""
+        X = batch.X
+        timesteps = batch.timesteps
+        assert timesteps is not None and timesteps.size(0) == len(batch)
+        t_lo, t_hi = float(torch.min(timesteps)), float(torch.max(timesteps))
+        assert t_lo == t_hi  # sampler.py:59-60
+        if self.use_cache and recompute_tokens is not None:
+            score, crf = self.score_model(batch, recompute_tokens=recompute_tokens, step=step, return_crf=True)
+            if self.score_model.cache is not None:
+                self.score_model.cache.update_crf(crf, timestep=t_lo)
+                self.score_model.cache.current_step = step
+        else:
+            score = self.score_model(batch)
+        output = self.noise_scheduler.step(model_output=score, timestep=timesteps[0].item(), sample=X)
+        X_prev = output.prev_sample
+        assert isinstance(X_prev, torch.Tensor)
+        return X_prev
+
+    # ------------------------------------------------------------------
+    def sample(self, num_samples: int, num_diffusion_steps: Optional[int] = None) -> torch.Tensor:
+        """sampler.py:105-215."""
+        if num_diffusion_steps is not None:
+            self._num_diffusion_steps = num_diffusion_steps
+        self.score_model.eval()
+        num_diffusion_steps = (self.score_model.num_training_steps if num_diffusion_steps is None
+                               else num_diffusion_steps)
+        self.noise_scheduler.set_timesteps(num_diffusion_steps)
+        sch = self.noise_scheduler
+        ts = sch.timesteps.to(torch.float32).contiguous()
+        ts_c = (C.c_float * num_diffusion_steps)(*ts.tolist())
+        step_size = float(sch.step_size)
+
+        model = self.score_model
+        ctx = model._ctx()
+        device = model.device
+        stream = N.current_stream_ptr(device)
+        all_samples = []
+        num_batches = max(1, num_samples // self.sample_batch_size)  # remainder dropped (Q10)
+        global_step = 0
+        sample_cursor = self.sample_offset
+        with torch.no_grad():
+            for batch_idx in range(num_batches):
+                batch_size = min(num_samples - batch_idx * self.sample_batch_size, self.sample_batch_size)
+                X = self.sample_prior(batch_size, _sample_offset=sample_cursor)
+                if self.use_cache and model.cache is not None and batch_idx == 0:
+                    model.cache.reset()  # sampler.py:151-153
+                    global_step = 0
+                use_cache = int(self.use_cache and model.cache is not None)
+                done = 0
+                while done < num_diffusion_steps:
+                    n = num_diffusion_steps - done
+                    z_ptr = None
+                    if self.rng == "torch" or self._injected is not None:
+                        n = min(n, max(1, self.z_chunk_steps))
+                        z = torch.empty((n,) + tuple(X.shape), device=device, dtype=torch.float32)
+                        for i in range(n):  # one randn_like per step, as the reference consumes its generator
+                            if self._injected is not None:
+                                z[i].copy_(self._next_injected(X.shape, device))
+                            else:
+                                z[i].normal_()
+                        z_ptr = z.data_ptr()
+                    rc = ctx.lib.ffd_sample_batch(ctx.handle, X.data_ptr(), batch_size, ts_c, num_diffusion_steps,
+                                                  step_size, done, n, self.seed, sample_cursor, z_ptr, use_cache,
+                                                  (global_step + done) if use_cache else 0, stream)
+                    N.check(rc, ctx.handle, "ffd_sample_batch")
+                    done += n
+                if use_cache:
+                    global_step += num_diffusion_steps
+                    model.cache.current_step = num_diffusion_steps - 1  # sampler.py:73-74 leaves step_idx
+                all_samples.append(X.cpu())
+                sample_cursor += batch_size
+        return torch.cat(all_samples, dim=0)
+
+    def sample_prior(self, batch_size: int, _sample_offset: int = 0) -> torch.Tensor:
+        """sampler.py:217-228."""
+        if not isinstance(self.noise_scheduler, SDE):
+            raise NotImplementedError("Scheduler not recognized.")
+        device = self.score_model.device
+        shape = (batch_size, self.max_len, self.n_channels)
+        if self._injected is not None:
+            if device.type != "cuda":
+                raise N.FFDError("sampling needs an MI355X (gfx950) device; there is no CPU fallback")
+            sch = self.noise_scheduler
+            z = self._next_injected(shape, device)
+            X = torch.empty(shape, device=device, dtype=torch.float32)
+            desc = sch._desc()
+            rc = N.lib().ffd_prior(C.byref(desc), X.data_ptr(), z.data_ptr(), sch._G_on(device).data_ptr(), 0, 0,
+                                   batch_size, self.max_len, self.n_channels, N.current_stream_ptr(device))
+            N.check(rc, None, "ffd_prior")
+        elif self.rng == "torch":
+            X = self.noise_scheduler.prior_sampling(shape, device=device)
+        else:
+            if device.type != "cuda":
+                raise N.FFDError("sampling needs an MI355X (gfx950) device; there is no CPU fallback")
+            sch = self.noise_scheduler
+            X = torch.empty(shape, device=device, dtype=torch.float32)
+            desc = sch._desc()
+            rc = N.lib().ffd_prior(C.byref(desc), X.data_ptr(), None, sch._G_on(device).data_ptr(), self.seed,
+                                   _sample_offset, batch_size, self.max_len, self.n_channels,
+                                   N.current_stream_ptr(device))
+            N.check(rc, None, "ffd_prior")
+        assert isinstance(X, torch.Tensor)
+        return X

@@ -1,0 +1,34 @@
+"""Batch sharding for multi-GPU sampling (host logic only).
+
+Sampling is embarrassingly parallel over the batch axis (no cross-sample operator in
+ScoreModule.forward, the SDE step or idft), so an N-GPU node is N independent shards:
+weights replicated (12.8 MB), contiguous sample ranges per rank, Philox noise keyed by
+*global* sample index so results do not depend on N.  There is no data-path collective;
+torch.distributed (RCCL on GPUs, gloo in CPU tests) only carries the barrier and the
+max-over-ranks of elapsed time.  With the E2-CRF cache each shard behaves as an
+independent reference run (its own step-0 table from its own element 0).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+
+def shard_range(num_samples: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """(offset, count) of `rank`'s contiguous sample range; counts differ by at most 1."""
+    assert world_size >= 1 and 0 <= rank < world_size and num_samples >= 0
+    base, rem = divmod(num_samples, world_size)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def reduce_max_seconds(seconds: float, device: Optional[object]) -> float:
+    """MAX over ranks of a wall-clock interval (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

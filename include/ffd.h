@@ -1,0 +1,211 @@
+/*
+ * libffd -- C ABI of the MI355X-native frequency-domain diffusion sampler.
+ *
+ * This is the drop-in boundary for the sampling hot path of
+ * NoakLiu/FastFourierDiffusion (`fdiff`).  The reference has no FFI layer of its
+ * own (it is pure Python on stock PyTorch ops), so each entry point below names
+ * the reference Python interface it replaces (file:line relative to the
+ * reference repository root).  Signatures use only plain C types: pointers are
+ * raw device (HBM) or host addresses, sizes are explicit, streams are passed as
+ * `void*` (a `hipStream_t`; NULL = the default stream).  No torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ffd_status on failure;
+ *     it never throws and never calls exit(); `ffd_last_error(ctx)` returns a
+ *     human-readable message for the most recent failure on that context;
+ *   - all device work is stream-ordered on the caller's stream: the functions
+ *     enqueue kernels and return without synchronising (exceptions are noted);
+ *   - I/O buffers are caller-owned and only borrowed for the stream-ordered
+ *     call; weights are copied (and re-packed) into context-owned HBM;
+ *   - one context per device; a context is not thread-safe, distinct contexts
+ *     are independent (no global state);
+ *   - tensors are dense row-major fp32: series X/score (B, L, C) with C
+ *     innermost and L the Fourier / attention axis (score_models.py:87-90,
+ *     fourier.py:12,24).
+ */
+#ifndef FFD_H
+#define FFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ffd_ctx ffd_ctx;
+
+typedef enum {
+  FFD_OK = 0,
+  FFD_ERR_INVALID = -1,     /* bad argument / shape (the reference's `assert`s, score_models.py:87-93) */
+  FFD_ERR_UNSUPPORTED = -2, /* configuration this build has no kernel for (reference: NotImplementedError) */
+  FFD_ERR_STATE = -3,       /* call order (e.g. forward before weights are finalised) */
+  FFD_ERR_HIP = -4,         /* a HIP runtime call failed; message carries hipGetErrorString */
+  FFD_ERR_NOMEM = -5
+} ffd_status;
+
+enum { FFD_MODEL_TRANSFORMER = 0, FFD_MODEL_LSTM = 1 };
+enum { FFD_SDE_VP = 0, FFD_SDE_VE = 1 };
+
+/* Model + scheduler hyper-parameters.
+ * Replaces the constructor arguments of ScoreModule / LSTMScoreModule
+ * (src/fdiff/models/score_models.py:25-37, 444-455) and of VPScheduler /
+ * VEScheduler (src/fdiff/schedulers/sde.py:91-97, 169-175). */
+typedef struct {
+  int32_t kind;            /* FFD_MODEL_* */
+  int32_t n_channels;      /* C */
+  int32_t max_len;         /* L */
+  int32_t d_model;         /* d   (transformer: 24, 60 or 72 in this build; lstm: same) */
+  int32_t n_head;          /* H   (ignored for lstm) */
+  int32_t num_layers;      /* NL */
+  int32_t dim_feedforward; /* F   (PyTorch default 2048, score_models.py:61-63); multiple of 64 */
+  int32_t sde;             /* FFD_SDE_* */
+  double sde_a;            /* VP: beta_min   | VE: sigma_min */
+  double sde_b;            /* VP: beta_max   | VE: sigma_max */
+  int32_t fourier_noise_scaling; /* SDE.noise_scaling (sde.py:16,49) */
+  double eps;              /* SDE.eps (sde.py:16) */
+} ffd_model_desc;
+
+/* E2-CRF cache configuration: the E2CRFCache kwargs the gate actually reads
+ * (src/fdiff/utils/caching.py:28-47,131-181: K and R; tau_0, tau_warn, ... are
+ * stored but never read by the reference). */
+typedef struct {
+  int32_t K;
+  int32_t R;
+} ffd_cache_cfg;
+
+/* E2CRFCache.stats / get_cache_stats counters (caching.py:107-111, 599-653). */
+typedef struct {
+  int64_t recompute_count;
+  int64_t cache_hit_count;
+  int64_t current_step;
+  int32_t table_allocated; /* k_cache_tensor is not None */
+  int32_t reserved;
+} ffd_cache_stats;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Build a context on HIP device `device`.  Replaces module construction +
+ * `.cuda()` (cmd/sample.py:68-77).  Fails with FFD_ERR_HIP if no gfx950 device
+ * is usable: there is no CPU fallback. */
+int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device);
+void ffd_destroy(ffd_ctx* ctx);
+const char* ffd_last_error(const ffd_ctx* ctx);
+/* Static description of the build ("libffd <ver> gfx950 ..."), usable without a device. */
+const char* ffd_version(void);
+
+/* ---- weights ----------------------------------------------------------- */
+
+/* Copy one parameter (host or device pointer, `n` floats) into the context.
+ * `name` is the reference state_dict key:
+ *   pos_encoder.embedding.weight (L,d)   time_encoder.W ((d+1)/2)
+ *   time_encoder.dense.{weight (d,d),bias}  embedder.{weight (d,C),bias}
+ *   unembedder.{weight (C,d),bias}
+ *   backbone.layers.{i}.self_attn.{in_proj_weight (3d,d),in_proj_bias,out_proj.weight,out_proj.bias}
+ *   backbone.layers.{i}.{linear1,linear2}.{weight,bias}  backbone.layers.{i}.{norm1,norm2}.{weight,bias}
+ *   backbone.{i}.{weight_ih_l0 (4d,d),weight_hh_l0 (4d,d),bias_ih_l0,bias_hh_l0}   (lstm)
+ * Replaces nn.Module.load_state_dict / load_from_checkpoint (cmd/sample.py:68-75). Synchronous. */
+int ffd_load_weight(ffd_ctx* ctx, const char* name, const float* data, size_t n);
+/* Validate that every parameter was supplied, apply the nn.Embedding(max_norm)
+ * renormalisation to its fixed point (transformer.py:13-15) and
+ * re-pack GEMM weights into MFMA fragment order.  Synchronous. */
+int ffd_finalize_weights(ffd_ctx* ctx);
+
+/* ---- scheduler tables (host only; no device needed) --------------------- */
+
+/* SDE.set_noise_scaling (sde.py:42-60): writes G[0..L). */
+int ffd_host_noise_scaling(int max_len, int fourier_noise_scaling, float* G_out);
+/* SDE.set_timesteps (sde.py:62-64): fp32 linspace(1, eps, n) and step_size = t[0]-t[1]. */
+int ffd_host_timesteps(int n, double eps, float* ts_out, float* step_size_out);
+/* E2CRFCache.determine_recompute_set (caching.py:131-181): the recompute set is
+ * always the prefix [0, n); returns n (>=0) for `step`. */
+int ffd_host_gate(int step, int max_len, int K, int R);
+
+/* ---- single operators (device pointers, stream ordered) ---------------- */
+
+/* ScoreModule.forward / LSTMScoreModule.forward (score_models.py:79-119, 486-511)
+ * without cache: score_out (B,L,C) <- model(x (B,L,C), t). All samples share `t`
+ * (sampler.py:59-60). */
+int ffd_score_forward(ffd_ctx* ctx, const float* x, float t, float* score_out, int B, void* stream);
+
+/* ScoreModule.forward(batch, recompute_tokens, step, return_crf=True)
+ * (score_models.py:79-194 + CachedTransformerEncoderLayer.forward,
+ * cached_transformer.py:106-329).  `n_recompute` is |recompute_tokens| (always
+ * the prefix [0,n), see ffd_host_gate).  Maintains the context's KV table
+ * (caching.py:302-396) and counters.  crf_out (NL,L,d) may be NULL. */
+int ffd_score_forward_cached(ffd_ctx* ctx, const float* x, float t, float* score_out, float* crf_out,
+                             int B, int n_recompute, void* stream);
+
+/* Scheduler hyper-parameters for the context-free scheduler operators below
+ * (VPScheduler / VEScheduler constructor arguments, sde.py:91-97, 169-175). */
+typedef struct {
+  int32_t sde;      /* FFD_SDE_* */
+  int32_t reserved;
+  double a;         /* VP: beta_min  | VE: sigma_min */
+  double b;         /* VP: beta_max  | VE: sigma_max */
+} ffd_sde_desc;
+
+/* VPScheduler.step / VEScheduler.step (sde.py:129-165, 215-246), in place on x (B,L,C).
+ * Context-free, like the reference scheduler objects: G (L floats, device) is the
+ * scheduler's noise scaling (ffd_host_noise_scaling uploaded by the caller).
+ * `t` is timesteps[i] widened to double (sampler.py:96-98).  z (B,L,C) supplies the
+ * N(0,1) draw; if NULL it is generated on device by Philox4x32-10 keyed by
+ * (seed, step) and counted by the global element index (sample_offset*L*C + i), so
+ * results do not depend on how a batch is sharded across GPUs. */
+int ffd_sde_step(const ffd_sde_desc* sde, float* x, const float* score, const float* G, double t,
+                 float step_size, const float* z, uint64_t seed, uint64_t sample_offset, int step, int B,
+                 int L, int C, void* stream);
+
+/* SDE.prior_sampling (sde.py:79-87, 125-127): x <- G (.) z  (VE: * sigma_max);
+ * z == NULL draws on device (Philox stream tag 0xFFFFFFFF). */
+int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G, uint64_t seed,
+              uint64_t sample_offset, int B, int L, int C, void* stream);
+
+/* fdiff.utils.fourier.dft / idft (fourier.py:8-52, 55-94): packed ortho rFFT and
+ * its inverse along dim 1 of (B,L,C).  `in` and `out` may not alias. Context-free. */
+int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream);
+int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream);
+
+/* ---- the sampling loop -------------------------------------------------- */
+
+/* E2CRFCache lifecycle used by DiffusionSampler (sampler.py:37-39,151-153):
+ * enable/disable (score_models.py:202-289), reset (caching.py:115-129). */
+int ffd_cache_enable(ffd_ctx* ctx, const ffd_cache_cfg* cfg);
+int ffd_cache_disable(ffd_ctx* ctx);
+int ffd_cache_reset(ffd_ctx* ctx);
+int ffd_cache_stats_get(const ffd_ctx* ctx, ffd_cache_stats* out);
+/* Copy the (NL,H,L,hd) K and V tables (caching.py:88-91; zeros until step 0 ran) into
+ * caller-owned device buffers; stream ordered.  Requires ffd_cache_enable. */
+int ffd_cache_tables_read(ffd_ctx* ctx, float* k_out, float* v_out, void* stream);
+
+/* One batch of DiffusionSampler.sample's inner loop (sampler.py:156-210): runs steps
+ * [first_step, first_step + n_run) of an n_steps-step reverse diffusion on x (B,L,C) in
+ * place, enqueuing every kernel on `stream` with no host synchronisation (one sync only
+ * when the timestep grid differs from the previous call's).
+ *   timesteps host array (n_steps) = noise_scheduler.timesteps (sde.py:62-64); the caller
+ *             supplies it because torch.linspace's last-ulp rounding depends on the host's
+ *             vector width; step_size = timesteps[0]-timesteps[1] in fp32.
+ *   z_inject  NULL, or (n_run,B,L,C) injected N(0,1) draws for the steps of this call;
+ *             NULL = Philox on device keyed (seed, step index) as in ffd_sde_step.
+ *   use_cache 0/1 (requires ffd_cache_enable); `global_step0` is the reference's
+ *             global_step (sampler.py:130,210) at `first_step`.
+ * x must already hold the prior sample (ffd_prior) or the state after step first_step-1. */
+int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int n_steps, float step_size,
+                     int first_step, int n_run, uint64_t seed, uint64_t sample_offset, const float* z_inject,
+                     int use_cache, int global_step0, void* stream);
+
+/* ---- introspection for benchmarks --------------------------------------- */
+
+/* Algorithmic FLOPs of one score evaluation per sample (SURVEY 8(d) formula) and of
+ * the fused FFN kernel per launch at batch B. */
+double ffd_flops_per_sample_step(const ffd_ctx* ctx, int cache_hit);
+double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B);
+/* Time `iters` launches of the dominant kernel (fused FFN+LN2 of layer 0) at batch B
+ * on `stream` with HIP events; returns average milliseconds per launch in *ms_out.
+ * Synchronous (benchmark helper only). */
+int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFD_H */

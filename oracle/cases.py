@@ -14,7 +14,7 @@ FFT_CASES = [(100, 3, 4, 11), (101, 3, 4, 12), (187, 1, 4, 13), (251, 4, 2, 14),
              (20, 3, 2, 16), (50, 3, 2, 17)]
 
 TABLE_LENS = [20, 50, 100, 101, 187, 251, 512]
-TABLE_STEPS = [8, 10, 50, 100, 120, 1000]
+TABLE_STEPS = [6, 8, 10, 20, 50, 100, 120, 1000]
 
 STEP_CASES = [
     dict(name="vp_ecg", sde="vp", sde_kwargs=VP, fourier=True, L=187, C=1, B=4, N=1000, idx=[0, 500, 999], seed=21),
