@@ -108,6 +108,16 @@ static bool hd_supported(int hd) { return hd == 4 || hd == 5 || hd == 6 || hd ==
 
 extern "C" {
 
+int ffd_tune(const char* key, int value) {
+  if (!key) return FFD_ERR_INVALID;
+  if (!strcmp(key, "ffn_mb")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return FFD_ERR_INVALID;
+    g_ffn_mb_override = value;
+    return FFD_OK;
+  }
+  return FFD_ERR_INVALID;
+}
+
 const char* ffd_version(void) { return "libffd 0.1 (gfx950, fp32 MFMA 16x16x4, wave64)"; }
 
 const char* ffd_last_error(const ffd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -65,53 +65,57 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, 
   const float4* W2q = reinterpret_cast<const float4*>(W2p) + (size_t)fc0 * CT * 64 + lane;
   const float4* b1q = reinterpret_cast<const float4*>(b1 + 16 * fc0) + (lane >> 4);
 
-  float4 w1n[G], w2n[CT], bn;
+  // Software pipeline with single register buffers: W1(ci+1) streams in while GEMM2(ci)
+  // runs (the W1 registers are dead after GEMM1), W2(ci+1) streams in while GEMM1(ci+1)
+  // runs.  Each load set therefore has >= 18*MB MFMAs (>= 4.6k cycles at MB = 8) to land
+  // from L2.  The sched_barriers pin the issue points: left alone, hipcc sinks each load
+  // next to its first use and exposes a vmcnt(0) stall every ~16 MFMAs.
+  float4 w1[G], w2[CT], bv;
+  auto load_w1 = [&](int c) {
 #pragma unroll
-  for (int g = 0; g < G; ++g) w1n[g] = W1q[g * 64];
+    for (int g = 0; g < G; ++g) w1[g] = W1q[((size_t)c * G + g) * 64];
+    bv = b1q[c * 4];
+  };
+  auto load_w2 = [&](int c) {
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) w2n[ct] = W2q[ct * 64];
-  bn = b1q[0];
-
+    for (int ct = 0; ct < CT; ++ct) w2[ct] = W2q[((size_t)c * CT + ct) * 64];
+  };
+  load_w1(0);
+  load_w2(0);
   for (int ci = 0; ci < nchunk; ++ci) {
-    float4 w1c[G], w2c[CT], bc = bn;
-#pragma unroll
-    for (int g = 0; g < G; ++g) w1c[g] = w1n[g];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) w2c[ct] = w2n[ct];
-    // prefetch the next chunk's fragments (clamped on the last iteration)
-    const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;
-#pragma unroll
-    for (int g = 0; g < G; ++g) w1n[g] = W1q[((size_t)nx * G + g) * 64];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) w2n[ct] = W2q[((size_t)nx * CT + ct) * 64];
-    bn = b1q[nx * 4];
-
-    // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D
+    const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;  // clamped: the last prefetch is a harmless re-read
+    // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
     f32x4 h[MB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{bc.x, bc.y, bc.z, bc.w};  // bias as the initial accumulator
+    for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float4 q = w1c[s >> 2];
+      const float4 q = w1[s >> 2];
       const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) h[mb] = mfma16(a, xf[mb][s], h[mb]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    load_w1(nx);
+    __builtin_amdgcn_sched_barrier(0);
+    // relu as one v_med3_f32 (x, 0, +inf) per element
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[mb][r] = fmaxf(h[mb][r], 0.f);
-
+      for (int r = 0; r < 4; ++r) h[mb][r] = __builtin_amdgcn_fmed3f(h[mb][r], 0.f, __builtin_inff());
     // GEMM2: Y^T += W2[:, chunk] H^T chunk ; accumulator register r is the k-step
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        const float4 q = w2c[ct];
+        const float4 q = w2[ct];
         const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
       }
+    __builtin_amdgcn_sched_barrier(0);
+    load_w2(nx);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // ---- deterministic cross-wave reduction through the LDS X tile ----
@@ -172,24 +176,28 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, 
   }
 }
 
+int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
+
 template <int D>
 static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s) {
-  // Tile height: the largest 16*MB rows that still yields >= ~2 workgroups per CU.
-  const int target = 2 * 256;
-  dim3 block(256);
-  if (cdiv(M, 128) >= target) {
-    hipLaunchKernelGGL((k_ffn_ln<D, 8>), dim3(cdiv(M, 128)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
-                       Y, M, F);
-  } else if (cdiv(M, 64) >= target) {
-    hipLaunchKernelGGL((k_ffn_ln<D, 4>), dim3(cdiv(M, 64)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
-                       Y, M, F);
-  } else if (cdiv(M, 32) >= target) {
-    hipLaunchKernelGGL((k_ffn_ln<D, 2>), dim3(cdiv(M, 32)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
-                       Y, M, F);
-  } else {
-    hipLaunchKernelGGL((k_ffn_ln<D, 1>), dim3(cdiv(M, 16)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, w.n2b,
-                       Y, M, F);
+  // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
+  // and is the default once the grid fills the chip; smaller tiles for small batches.
+  int mb = g_ffn_mb_override;
+  if (mb != 1 && mb != 2 && mb != 4 && mb != 8) {
+    const int target = 2 * 256;
+    mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
+  dim3 block(256);
+#define FFD_LAUNCH_FFN(MBV)                                                                                     \
+  hipLaunchKernelGGL((k_ffn_ln<D, MBV>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, \
+                     w.n2b, Y, M, F)
+  switch (mb) {
+    case 8: FFD_LAUNCH_FFN(8); break;
+    case 4: FFD_LAUNCH_FFN(4); break;
+    case 2: FFD_LAUNCH_FFN(2); break;
+    default: FFD_LAUNCH_FFN(1); break;
+  }
+#undef FFD_LAUNCH_FFN
   return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
                                 const float* beta, float* Y, int M, int D, hipStream_t s);
 // Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s);
+extern int g_ffn_mb_override;
 
 // attention over qkv (M x 3d row-major, [q|k|v]); tokens >= n_own take K/V from the
 // (H,L,hd) tables kt/vt instead of the sample's own rows. out: (M x d).

@@ -194,6 +194,10 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
                      int first_step, int n_run, uint64_t seed, uint64_t sample_offset, const float* z_inject,
                      int use_cache, int global_step0, void* stream);
 
+/* Process-wide tuning knob for experiments (results never change, only tiling):
+ *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8  -- rows/16 per workgroup of the fused FFN. */
+int ffd_tune(const char* key, int value);
+
 /* ---- introspection for benchmarks --------------------------------------- */
 
 /* Algorithmic FLOPs of one score evaluation per sample (SURVEY 8(d) formula) and of
