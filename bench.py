@@ -68,14 +68,27 @@ def run_steps(model, sampler, X, ts_c, n_total, step_size, first, n_run, use_cac
     N.check(rc, ctx.handle, "ffd_sample_batch")
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask, cgroup quota, and the GPU
+    box's per-GPU share (16) -- os.cpu_count() reports the whole 256-thread host."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("FFD_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sd, L, Cn, NL, H, kind):
     """The oracle (CPU restatement of the reference path, torch-CPU fp32, all host cores)
     on a bounded sample of the same workload."""
     from oracle import ffd_oracle as O
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    B, warm, steps = 32, 1, 12
+    B, warm, steps = 32, 2, 20
     sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
     G = O.noise_scaling(L, True)
     ts, dt = O.timesteps(1000)
