@@ -24,7 +24,7 @@
 namespace ffd {
 
 template <int D, int MB>
-__global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, const float* __restrict__ W1p,
+__global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* __restrict__ X, const float* __restrict__ W1p,
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
                                                   const float* __restrict__ b2, const float* __restrict__ gam,
                                                   const float* __restrict__ bet, float* __restrict__ Y, int M,
@@ -34,16 +34,24 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, 
   constexpr int G = dpack_groups(D);
   constexpr int CT = cdiv(D, 16);
   constexpr int R = 16 * MB;
-  __shared__ float xs[R * S];
+  constexpr int S2 = ((D + 3) / 4) * 4 + 4;  // partial-sum row stride (16-byte aligned rows)
+  __shared__ __align__(16) float xs[R * S];
+  __shared__ __align__(16) float red[3 * R * S2];
 
   const int m0 = blockIdx.x * R;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // ---- stage the X tile (coalesced) and pull this wave's B fragments ----
-  for (int idx = threadIdx.x; idx < R * D; idx += 256) {
-    int r = idx / D, k = idx - r * D;
-    int m = m0 + r;
-    xs[r * S + k] = (m < M) ? X[(size_t)m * D + k] : 0.f;
+  // ---- stage the X tile (coalesced float4) and pull this wave's B fragments ----
+  {
+    const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)m0 * D);
+    const int rows_valid = min(R, M - m0);
+    for (int i4 = threadIdx.x; i4 < R * D / 4; i4 += 256) {
+      const int r = (4 * i4) / D, k = 4 * i4 - r * D;
+      float4 v = (r < rows_valid) ? X4[i4] : float4{0.f, 0.f, 0.f, 0.f};
+      float2* dst = reinterpret_cast<float2*>(&xs[r * S + k]);  // S even: 8-byte aligned
+      dst[0] = float2{v.x, v.y};
+      dst[1] = float2{v.z, v.w};
+    }
   }
   __syncthreads();
   float xf[MB][KS];
@@ -118,21 +126,30 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, 
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  // ---- deterministic cross-wave reduction through the LDS X tile ----
-  // xs holds X (the residual); wave w adds its partial after waves < w.
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
+  // ---- deterministic cross-wave reduction: wave 0 adds its partial into the LDS X tile
+  // (= the residual), waves 1..3 park theirs in red[]; one barrier; every thread then sums
+  // x + p0 (already in xs) + p1 + p2 + p3 + b2 in that fixed order.
+  if (wave == 0) {
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+      for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + 4 * (lane >> 4) + r;
-            if (c < D) xs[(16 * mb + (lane & 15)) * S + c] += yacc[ct][mb][r];
-          }
-    }
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * ct + 4 * (lane >> 4) + r;
+          if (c < D) xs[(16 * mb + (lane & 15)) * S + c] += yacc[ct][mb][r];
+        }
+  } else {
+    float* rw = red + (size_t)(wave - 1) * R * S2;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const int c = 16 * ct + 4 * (lane >> 4);
+        if (c < D)
+          *reinterpret_cast<float4*>(&rw[(16 * mb + (lane & 15)) * S2 + c]) =
+              float4{yacc[ct][mb][0], yacc[ct][mb][1], yacc[ct][mb][2], yacc[ct][mb][3]};
+      }
   }
   __syncthreads();
 
@@ -147,7 +164,11 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln(const float* __restrict__ X, 
     const int c = sub + i * TPR;
     float v = 0.f;
     if (c < D) {
-      v = xs[row * S + c] + b2[c];
+      v = xs[row * S + c];
+      v += red[(0 * R + row) * S2 + c];
+      v += red[(1 * R + row) * S2 + c];
+      v += red[(2 * R + row) * S2 + c];
+      v += b2[c];
       sum += v;
     }
     vals[i] = v;
