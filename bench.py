@@ -122,6 +122,7 @@ def main() -> None:
     ap.add_argument("--cache", action="store_true", help="time the E2-CRF cached path (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cache-ratio side measurements")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for ffd_tune (experiments)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +144,9 @@ def main() -> None:
     from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
     from fastfourierdiffusion_amd.sharding import reduce_max_seconds
 
+    for kv in args.tune:
+        k, v = kv.split("=")
+        assert N.lib().ffd_tune(k.encode(), int(v)) == 0, kv
     model, sch, sd = build_model(device, args.workload)
     B, L, Cn = args.batch, model.max_len, model.n_channels
     n_total = 1000

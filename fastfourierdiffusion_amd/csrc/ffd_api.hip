@@ -103,6 +103,8 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
   return FFD_OK;
 }
 
+static int g_bench_kernel = 0;
+
 static bool d_supported(int d) { return d == 24 || d == 60 || d == 72; }
 static bool hd_supported(int hd) { return hd == 4 || hd == 5 || hd == 6 || hd == 8; }
 
@@ -113,6 +115,30 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "ffn_mb")) {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return FFD_ERR_INVALID;
     g_ffn_mb_override = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "bench_kernel")) {  // what ffd_bench_ffn times: 0 k_ffn_ln, 1 k_layer, 2 k_layer + next QKV
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_bench_kernel = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "fuse_layer")) {
+    if (value < -1 || value > 1) return FFD_ERR_INVALID;
+    g_fuse_layer = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "dbg")) {
+    g_dbg = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "attn_qg")) {
+    if (value < 0 || value > 3) return FFD_ERR_INVALID;
+    g_attn_qg = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "attn_impl")) {
+    if (value != 0 && value != 1) return FFD_ERR_INVALID;
+    g_attn_impl = value;
     return FFD_OK;
   }
   return FFD_ERR_INVALID;
@@ -417,32 +443,52 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
     else mode = MIXED;
   }
   const size_t lt = (size_t)H * L * hd;  // table floats per layer
+  // q / k / v regions, head-major (B,H,L,hd)
+  float* qreg = ctx->qkv;
+  float* kreg = ctx->qkv + (size_t)M * d;
+  float* vreg = ctx->qkv + 2 * (size_t)M * d;
+  const int nreg = (mode == PURE) ? 1 : 3;
+  const int n_own = (mode == PURE) ? 0 : (mode == MIXED) ? n_rec : L;
+  const bool fused = g_fuse_layer == 1 || (g_fuse_layer < 0 && cdiv(M, 64) >= 256);
+  float* cur = ctx->h0;  // layer input / residual
+  float* alt = ctx->h1;
+  auto proj_w = [&](int i) { return mode == PURE ? ctx->packed[i].q_wp : ctx->packed[i].in_wp; };
+  if (fused)
+    HIPCHECK(launch_linear_hm(cur, proj_w(0), ctx->layers[0].in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
   for (int i = 0; i < m.num_layers; ++i) {
     const LayerWeights& w = ctx->layers[i];
     const LayerPacked& pk = ctx->packed[i];
     float* kt = ctx->kt ? ctx->kt + i * lt : nullptr;
     float* vt = ctx->vt ? ctx->vt + i * lt : nullptr;
-    if (mode == PURE) {
-      HIPCHECK(launch_linear(ctx->h0, pk.q_wp, w.in_b, ctx->qkv, M, d, d, 3 * d, s));
-      HIPCHECK(launch_attention(ctx->qkv, kt, vt, ctx->attn, B, L, H, hd, 0, s));
-    } else if (mode == MIXED) {
-      HIPCHECK(launch_linear(ctx->h0, pk.in_wp, w.in_b, ctx->qkv, M, 3 * d, d, 3 * d, s));
-      HIPCHECK(launch_attention(ctx->qkv, kt, vt, ctx->attn, B, L, H, hd, n_rec, s));
-      // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
-      HIPCHECK(launch_kv_store(ctx->qkv + d, 3 * d, kt, vt, L, H, hd, n_rec, s));
+    const bool tables = (mode == PURE || mode == MIXED);
+    if (!fused) HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
+    HIPCHECK(launch_attention(qreg, kreg, vreg, tables ? kt : nullptr, tables ? vt : nullptr, ctx->attn, B, L, H, hd,
+                              n_own, s));
+    if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
+      HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
+    if (fused) {
+      NextProj nx{};
+      if (i + 1 < m.num_layers) {
+        nx.wp = proj_w(i + 1);
+        nx.bias = ctx->layers[i + 1].in_b;
+        nx.q = qreg, nx.k = kreg, nx.v = vreg;
+        nx.nreg = nreg, nx.L = L, nx.H = H, nx.hd = hd;
+      }
+      HIPCHECK(launch_layer(ctx->attn, cur, w, alt, nx, M, d, F, s));
+      float* t = cur;
+      cur = alt;
+      alt = t;
     } else {
-      HIPCHECK(launch_linear(ctx->h0, pk.in_wp, w.in_b, ctx->qkv, M, 3 * d, d, 3 * d, s));
-      HIPCHECK(launch_attention(ctx->qkv, nullptr, nullptr, ctx->attn, B, L, H, hd, L, s));
+      HIPCHECK(launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+      HIPCHECK(launch_ffn_ln(alt, w, cur, M, d, F, s));
     }
-    HIPCHECK(launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, ctx->h0, w.n1w, w.n1b, ctx->h1, M, d, s));
-    HIPCHECK(launch_ffn_ln(ctx->h1, w, ctx->h0, M, d, F, s));
     if (mode == FULL) {
-      // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158)
-      HIPCHECK(launch_linear(ctx->h0, pk.kv_wp, w.in_b + d, ctx->kvtmp, L, 2 * d, d, 2 * d, s));
-      HIPCHECK(launch_kv_store(ctx->kvtmp, 2 * d, kt, vt, L, H, hd, L, s));
+      // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
+      // straight into this layer's tables: head-major (1,H,L,hd) == table layout
+      HIPCHECK(launch_linear_hm(cur, pk.kv_wp, w.in_b + d, kt, vt, nullptr, L, 2, d, L, H, hd, s));
     }
     if (n_rec >= 0 && crf_out)  // crf[l] = h_l[0]  (score_models.py:181-194)
-      HIPCHECK(hipMemcpyAsync(crf_out + (size_t)i * L * d, ctx->h0, sizeof(float) * L * d, hipMemcpyDeviceToDevice, s));
+      HIPCHECK(hipMemcpyAsync(crf_out + (size_t)i * L * d, cur, sizeof(float) * L * d, hipMemcpyDeviceToDevice, s));
   }
   if (n_rec >= 0) {  // counters, caching.py:283,299,396
     if (mode == FULL) ctx->stats.recompute_count += (int64_t)L * m.num_layers, ctx->table_allocated = true;
@@ -453,7 +499,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
       ctx->table_allocated = true;
     }
   }
-  HIPCHECK(launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C, d,
+  HIPCHECK(launch_unembed(cur, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C, d,
                           s));
   return FFD_OK;
 }
@@ -698,12 +744,24 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);
   HIPCHECK(hipGetLastError());
-  for (int i = 0; i < 3; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+  hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->attn, (size_t)M * d, 0x1234567u);
+  HIPCHECK(hipGetLastError());
+  NextProj nx{};
+  if (g_bench_kernel == 2 && m.num_layers > 1) {
+    nx.wp = ctx->packed[1].in_wp, nx.bias = ctx->layers[1].in_b;
+    nx.q = ctx->qkv, nx.k = ctx->qkv + (size_t)M * d, nx.v = ctx->qkv + 2 * (size_t)M * d;
+    nx.nreg = 3, nx.L = m.max_len, nx.H = m.n_head, nx.hd = d / m.n_head;
+  }
+  auto run = [&]() -> hipError_t {
+    if (g_bench_kernel == 0) return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s);
+    return launch_layer(ctx->attn, ctx->h1, ctx->layers[0], ctx->h0, nx, M, d, m.dim_feedforward, s);
+  };
+  for (int i = 0; i < 3; ++i) HIPCHECK(run());
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
   HIPCHECK(hipEventRecord(e0, s));
-  for (int i = 0; i < iters; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+  for (int i = 0; i < iters; ++i) HIPCHECK(run());
   HIPCHECK(hipEventRecord(e1, s));
   HIPCHECK(hipEventSynchronize(e1));
   float ms = 0.f;

@@ -67,7 +67,8 @@ __device__ __forceinline__ void attend_keys(const float* __restrict__ kv, float 
 }
 
 template <int HD, int QPL>
-__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv, const float* __restrict__ kt,
+__global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qg, const float* __restrict__ kg,
+                                                   const float* __restrict__ vg, const float* __restrict__ kt,
                                                    const float* __restrict__ vt, float* __restrict__ out, int B,
                                                    int L, int H, int n_own) {
   constexpr int KVS = KvStride<HD>::value;
@@ -81,19 +82,20 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   float* kv = lds + (size_t)wave * L * KVS;
 
   // ---- stage K/V rows of this head: [key][k0..k(hd-1), v0..v(hd-1), pad] ----
+  // q/k/v are head-major (B,H,L,hd): the (b,h) slice is one contiguous run, as are the tables.
+  const size_t slice = (size_t)pair * L * HD;
   if (active) {
+    const float* kown = kg + slice;
+    const float* vown = vg + slice;
+    const float* ktab = kt ? kt + (size_t)h * L * HD : kown;
+    const float* vtab = vt ? vt + (size_t)h * L * HD : vown;
+    const int own_elems = n_own * HD;
+#pragma unroll 4
     for (int idx = lane; idx < L * HD; idx += 64) {
       const int j = idx / HD, e = idx - j * HD;
-      float kx, vx;
-      if (j < n_own) {
-        const float* row = qkv + ((size_t)b * L + j) * (3 * d) + h * HD + e;
-        kx = row[d];
-        vx = row[2 * d];
-      } else {
-        const size_t t = ((size_t)h * L + j) * HD + e;
-        kx = kt[t];
-        vx = vt[t];
-      }
+      const bool own = idx < own_elems;
+      const float kx = (own ? kown : ktab)[idx];
+      const float vx = (own ? vown : vtab)[idx];
       kv[j * KVS + e] = kx;
       kv[j * KVS + HD + e] = vx;
     }
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   for (int qi = 0; qi < QPL; ++qi) {
     int l = qi * 64 + lane;
     if (l >= L) l = L - 1;
-    const float* row = qkv + ((size_t)b * L + l) * (3 * d) + h * HD;
+    const float* row = qg + slice + (size_t)l * HD;
 #pragma unroll
     for (int e = 0; e < HD; ++e) q[qi][e] = row[e] * c, acc[qi][e] = 0.f;
     mrun[qi] = -INFINITY, lrun[qi] = 0.f;
@@ -130,44 +132,238 @@ __global__ __launch_bounds__(256) void k_attention(const float* __restrict__ qkv
   }
 }
 
+// ---------------------------------------------------------------------------
+// Hybrid form (default): Q K^T on the matrix cores, softmax + P V on the vector ALU.
+//   S^T tile (32 keys x 32 queries) = K_tile (32 x hd) . Qs_tile^T (hd x 32) is ceil(hd/2)
+//   v_mfma_f32_32x32x2_f32 (no padding waste at hd = 6).  Its accumulator layout puts the
+//   query on the lane (l & 31) and 16 keys on the registers
+//       key = 32 kt + (r & 3) + 8 (r >> 2) + 4 (l >> 5),
+//   so softmax over keys is an in-lane reduction and P V is hd FMAs per score with V rows
+//   broadcast-read from LDS (address depends only on the lane half).  The two lane halves
+//   keep separate online-softmax states for the same query and are merged once per
+//   q-tile.  QG q-tiles share every V read.  K fragments of all key tiles stay in VGPRs.
+// ---------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int HD, int QG>
+__global__ __launch_bounds__(256) void k_attention_mfma(const float* __restrict__ qg, const float* __restrict__ kg,
+                                                        const float* __restrict__ vg, const float* __restrict__ kt,
+                                                        const float* __restrict__ vt, float* __restrict__ out,
+                                                        int B, int L, int H, int n_own) {
+  constexpr int KST = (HD + 1) / 2;  // MFMA k-steps
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wpb = blockDim.x >> 6;
+  const int pair = blockIdx.x * wpb + wave;
+  const int d = H * HD;
+  const bool active = pair < B * H;
+  const int b = active ? pair / H : 0, h = active ? pair % H : 0;
+  const int KT = (L + 31) >> 5;
+  const int Lp = KT * 32;
+  // per-wave LDS: V rows [Lp][8] (zero padded) then K^T [2*KST][Lp]
+  float* vs = lds + (size_t)wave * Lp * (8 + 2 * KST);
+  float* kts = vs + (size_t)Lp * 8;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // zero the padded images, then fill from the contiguous head-major slices (coalesced)
+  for (int idx = lane; idx < Lp * (8 + 2 * KST); idx += 64) vs[idx] = 0.f;
+  const size_t slice = (size_t)pair * L * HD;
+  if (active) {
+    const float* kown = kg + slice;
+    const float* vown = vg + slice;
+    const float* ktab = kt ? kt + (size_t)h * L * HD : kown;
+    const float* vtab = vt ? vt + (size_t)h * L * HD : vown;
+    const int own_elems = n_own * HD;
+#pragma unroll 4
+    for (int idx = lane; idx < L * HD; idx += 64) {
+      const int j = idx / HD, e = idx - j * HD;
+      const bool own = idx < own_elems;
+      const float kx = (own ? kown : ktab)[idx];
+      const float vx = (own ? vown : vtab)[idx];
+      vs[j * 8 + e] = vx;
+      kts[e * Lp + j] = kx;
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  const float c = 1.4426950408889634f / sqrtf((float)HD);
+  const int QT = KT;
+  for (int qt0 = 0; qt0 < QT; qt0 += QG) {
+    float qf[QG][KST], m[QG], lsum[QG], acc[QG][HD];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      int q = 32 * (qt0 + g) + l31;
+      if (q >= L) q = L - 1;
+#pragma unroll
+      for (int s = 0; s < KST; ++s) {
+        const int e = 2 * s + half;
+        qf[g][s] = (e < HD) ? qg[slice + (size_t)q * HD + e] * c : 0.f;
+      }
+      m[g] = -INFINITY, lsum[g] = 0.f;
+#pragma unroll
+      for (int e = 0; e < HD; ++e) acc[g][e] = 0.f;
+    }
+#pragma unroll 1
+    for (int t = 0; t < KT; ++t) {
+      float kf[KST];
+#pragma unroll
+      for (int s = 0; s < KST; ++s) kf[s] = kts[(2 * s + half) * Lp + 32 * t + l31];
+      f32x16 sc[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KST; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        sc[g] = z;
+      }
+      const int kbase = 32 * t + 4 * half;
+      if (32 * t + 32 > L) {  // last, ragged key tile: mask keys >= L
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+#pragma unroll
+          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        float bm = sc[g][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) bm = fmaxf(bm, sc[g][r]);
+        const float mnew = fmaxf(m[g], bm);
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float corr = __builtin_amdgcn_exp2f(m[g] - msafe);
+        m[g] = mnew;
+        float l = lsum[g] * corr;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) acc[g][e] *= corr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(sc[g][r] - msafe);
+          sc[g][r] = p;
+          l += p;
+        }
+        lsum[g] = l;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* vr = vs + (size_t)(kbase + (r & 3) + 8 * (r >> 2)) * 8;
+        float vv[8];
+        const float4 v0 = *reinterpret_cast<const float4*>(vr);
+        vv[0] = v0.x, vv[1] = v0.y, vv[2] = v0.z, vv[3] = v0.w;
+        if (HD > 4) {
+          const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
+          vv[4] = v1.x, vv[5] = v1.y, vv[6] = v1.z, vv[7] = v1.w;
+        }
+#pragma unroll
+        for (int g = 0; g < QG; ++g)
+#pragma unroll
+          for (int e = 0; e < HD; ++e) acc[g][e] = fmaf(sc[g][r], vv[e], acc[g][e]);
+      }
+    }
+    // ---- merge the two lane halves (same query, disjoint keys) and store ----
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      const float mo = __shfl_xor(m[g], 32);
+      const float mm = fmaxf(m[g], mo);
+      const float f = (m[g] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m[g] - mm);
+      float l = lsum[g] * f;
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      const int q = 32 * (qt0 + g) + l31;
+      float o[HD];
+#pragma unroll
+      for (int e = 0; e < HD; ++e) {
+        float a = acc[g][e] * f;
+        a += __shfl_xor(a, 32);
+        o[e] = a * inv;
+      }
+      if (half == 0 && q < L && qt0 + g < QT) {
+        float* orow = out + ((size_t)b * L + q) * d + h * HD;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) orow[e] = o[e];
+      }
+    }
+  }
+}
+
+template <int HD, int QG>
+static hipError_t launch_attn_mfma_t(const float* q, const float* k, const float* v, const float* kt,
+                                     const float* vt, float* out, int B, int L, int H, int n_own, hipStream_t s) {
+  constexpr int KST = (HD + 1) / 2;
+  const int Lp = ((L + 31) / 32) * 32;
+  const size_t per_wave = (size_t)Lp * (8 + 2 * KST) * sizeof(float);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
+  const int pairs = B * H;
+  hipLaunchKernelGGL((k_attention_mfma<HD, QG>), dim3(cdiv(pairs, wpb)), dim3(64 * wpb), per_wave * wpb, s, q, k, v,
+                     kt, vt, out, B, L, H, n_own);
+  return hipGetLastError();
+}
+
+int g_attn_qg = 0;  // 0 heuristic; 1/2/3 force the q-tile group size (ffd_tune "attn_qg")
+
+template <int HD>
+static hipError_t launch_attn_mfma_hd(const float* q, const float* k, const float* v, const float* kt,
+                                      const float* vt, float* out, int B, int L, int H, int n_own, hipStream_t s) {
+  const int QT = (L + 31) / 32;
+  if (g_attn_qg == 1 || QT == 1) return launch_attn_mfma_t<HD, 1>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (g_attn_qg == 2) return launch_attn_mfma_t<HD, 2>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (g_attn_qg == 3) return launch_attn_mfma_t<HD, 3>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (QT % 3 == 0) return launch_attn_mfma_t<HD, 3>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  return launch_attn_mfma_t<HD, 2>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+}
+
+int g_attn_impl = 0;  // 0 = hybrid MFMA/VALU (default), 1 = pure VALU (ffd_tune "attn_impl")
+
 template <int HD, int QPL>
-static hipError_t launch_attn_t(const float* qkv, const float* kt, const float* vt, float* out, int B, int L, int H,
-                                int n_own, hipStream_t s) {
+static hipError_t launch_attn_t(const float* q, const float* k, const float* v, const float* kt, const float* vt,
+                                float* out, int B, int L, int H, int n_own, hipStream_t s) {
   constexpr int KVS = KvStride<HD>::value;
   const size_t per_wave = (size_t)L * KVS * sizeof(float);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
   const int pairs = B * H;
-  hipLaunchKernelGGL((k_attention<HD, QPL>), dim3(cdiv(pairs, wpb)), dim3(64 * wpb), per_wave * wpb, s, qkv, kt, vt,
-                     out, B, L, H, n_own);
+  hipLaunchKernelGGL((k_attention<HD, QPL>), dim3(cdiv(pairs, wpb)), dim3(64 * wpb), per_wave * wpb, s, q, k, v, kt,
+                     vt, out, B, L, H, n_own);
   return hipGetLastError();
 }
 
 template <int HD>
-static hipError_t launch_attn_hd(const float* qkv, const float* kt, const float* vt, float* out, int B, int L, int H,
-                                 int n_own, hipStream_t s) {
+static hipError_t launch_attn_hd(const float* qkv, const float* k, const float* v, const float* kt, const float* vt,
+                                 float* out, int B, int L, int H, int n_own, hipStream_t s) {
   const int qpl = cdiv(L, 64);
   switch (qpl) {
-    case 1: return launch_attn_t<HD, 1>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 2: return launch_attn_t<HD, 2>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 3: return launch_attn_t<HD, 3>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 4: return launch_attn_t<HD, 4>(qkv, kt, vt, out, B, L, H, n_own, s);
+    case 1: return launch_attn_t<HD, 1>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 2: return launch_attn_t<HD, 2>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 3: return launch_attn_t<HD, 3>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 4: return launch_attn_t<HD, 4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
     case 5:
-    case 6: return launch_attn_t<HD, 6>(qkv, kt, vt, out, B, L, H, n_own, s);
+    case 6: return launch_attn_t<HD, 6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
     case 7:
-    case 8: return launch_attn_t<HD, 8>(qkv, kt, vt, out, B, L, H, n_own, s);
+    case 8: return launch_attn_t<HD, 8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
     default: return hipErrorInvalidValue;  // L > 512
   }
 }
 
-hipError_t launch_attention(const float* qkv, const float* kt, const float* vt, float* out, int B, int L, int H,
-                            int hd, int n_own, hipStream_t s) {
+hipError_t launch_attention(const float* qkv, const float* k, const float* v, const float* kt, const float* vt,
+                            float* out, int B, int L, int H, int hd, int n_own, hipStream_t s) {
   if (B <= 0) return hipSuccess;
+  if (g_attn_impl == 0) {
+    switch (hd) {
+      case 4: return launch_attn_mfma_hd<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 5: return launch_attn_mfma_hd<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 6: return launch_attn_mfma_hd<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 8: return launch_attn_mfma_hd<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (hd) {
-    case 4: return launch_attn_hd<4>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 5: return launch_attn_hd<5>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 6: return launch_attn_hd<6>(qkv, kt, vt, out, B, L, H, n_own, s);
-    case 8: return launch_attn_hd<8>(qkv, kt, vt, out, B, L, H, n_own, s);
+    case 4: return launch_attn_hd<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 5: return launch_attn_hd<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 6: return launch_attn_hd<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    case 8: return launch_attn_hd<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
     default: return hipErrorInvalidValue;
   }
 }

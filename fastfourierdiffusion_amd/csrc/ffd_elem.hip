@@ -115,26 +115,36 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 // ---------------------------------------------------------------------------
 __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ We, const float* __restrict__ be,
                         const float* __restrict__ pos, const float* __restrict__ temb, float* __restrict__ h,
-                        size_t total, int L, int C, int D) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    size_t row = i / D;
-    int j = (int)(i - row * D);
-    int l = (int)(row % L);
-    const float* x = X + row * C;
-    float v = be[j];
-    for (int c = 0; c < C; ++c) v = fmaf(x[c], We[j * C + c], v);
-    if (pos) v += pos[(size_t)l * D + j];
-    v += temb[j];
-    h[i] = v;
+                        unsigned total4, int L, int C, int D) {
+  // one float4 of h per thread (D % 4 == 0); 32-bit index math only
+  for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
+    const unsigned row = (4u * i4) / (unsigned)D;
+    const int j = (int)(4u * i4 - row * (unsigned)D);
+    const int l = (int)(row % (unsigned)L);
+    const float* x = X + (size_t)row * C;
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = be[j + q];
+    for (int c = 0; c < C; ++c) {
+      const float xc = x[c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = fmaf(xc, We[(j + q) * C + c], v[q]);
+    }
+    if (pos) {
+      const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)l * D + j);
+      v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
+    }
+    const float4 t = *reinterpret_cast<const float4*>(temb + j);
+    reinterpret_cast<float4*>(h)[i4] = float4{v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w};
   }
 }
 
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
                         float* h, int B, int L, int C, int D, hipStream_t s) {
-  size_t total = (size_t)B * L * D;
-  size_t blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_embed, dim3((unsigned)blocks), dim3(256), 0, s, X, We, be, pos, temb, h, total, L, C, D);
+  const unsigned total4 = (unsigned)((size_t)B * L * D / 4);
+  unsigned blocks = (total4 + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, h, total4, L, C, D);
   return hipGetLastError();
 }
 
@@ -242,7 +252,7 @@ __global__ void k_sde_step(float* __restrict__ x, const float* __restrict__ scor
     load_normals(z, i0, n, seed, elem_offset, step, zz);
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
-      int l = (int)((i / C) % L);
+      const int l = (int)(((unsigned)i / (unsigned)C) % (unsigned)L);
       float g = __fmul_rn(p.cs, G[l]);
       float g2 = __fmul_rn(g, g);
       float xi = x[i];
@@ -275,7 +285,7 @@ __global__ void k_prior(float* __restrict__ x, const float* __restrict__ z, cons
     load_normals(z, i0, n, seed, elem_offset, 0xFFFFFFFFu, zz);
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
-      int l = (int)((i / C) % L);
+      const int l = (int)(((unsigned)i / (unsigned)C) % (unsigned)L);
       float v0 = __fmul_rn(G[l], zz[j]);
       x[i] = (scale == 1.0f) ? v0 : __fmul_rn(scale, v0);
     }
@@ -293,27 +303,25 @@ hipError_t launch_prior(float* x, const float* z, const float* G, float scale, u
 }
 
 // ---------------------------------------------------------------------------
-// KV table store: table[h][l][e] <- kv[l][off + h*hd + e], l < n (sample 0 only, Q1)
+// KV table store: table[h][l][:] <- sample 0's head-major K/V rows, l < n (Q1)
 // ---------------------------------------------------------------------------
-__global__ void k_kv_store(const float* __restrict__ kv, int ldkv, float* __restrict__ kt, float* __restrict__ vt,
-                           int L, int H, int hd, int n) {
-  const int d = H * hd;
-  const int total = n * d;
+__global__ void k_kv_store(const float* __restrict__ k, const float* __restrict__ v, float* __restrict__ kt,
+                           float* __restrict__ vt, int L, int H, int hd, int n) {
+  const int per_head = n * hd;
+  const int total = H * per_head;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int l = i / d;
-    int c = i - l * d;
-    int h = c / hd, e = c - h * hd;
-    size_t dst = ((size_t)h * L + l) * hd + e;
-    kt[dst] = kv[(size_t)l * ldkv + c];
-    vt[dst] = kv[(size_t)l * ldkv + d + c];
+    const int h = i / per_head, r = i - h * per_head;
+    const size_t off = (size_t)h * L * hd + r;  // sample 0: (0*H + h)*L*hd
+    kt[off] = k[off];
+    vt[off] = v[off];
   }
 }
 
-hipError_t launch_kv_store(const float* kv, int ldkv, float* kt, float* vt, int L, int H, int hd, int n,
+hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt, int L, int H, int hd, int n,
                            hipStream_t s) {
   if (n <= 0) return hipSuccess;
   int blocks = cdiv(n * H * hd, 256);
-  hipLaunchKernelGGL(k_kv_store, dim3(blocks), dim3(256), 0, s, kv, ldkv, kt, vt, L, H, hd, n);
+  hipLaunchKernelGGL(k_kv_store, dim3(blocks), dim3(256), 0, s, k, v, kt, vt, L, H, hd, n);
   return hipGetLastError();
 }
 

@@ -50,6 +50,15 @@ struct LayerWeights {
   const float *w2p;     // w2pack
 };
 
+// The next layer's input projection, fused as the epilogue of k_layer (nreg = 0: none,
+// 1: Q only (pure-cache step), 3: Q,K,V); outputs are head-major (B,H,L,hd).
+struct NextProj {
+  const float* wp;
+  const float* bias;
+  float *q, *k, *v;
+  int nreg, L, H, hd;
+};
+
 hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s);
 hipError_t launch_pack_w2(const float* W2, float* W2p, int D, int F, hipStream_t s);
 hipError_t launch_renorm_rows(float* W, int rows, int D, float max_norm, hipStream_t s);
@@ -84,14 +93,26 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
                                 const float* beta, float* Y, int M, int D, hipStream_t s);
 // Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s);
+// out-proj + LN1 + FFN + LN2 (+ next layer's projection) for 64-row tiles in one launch
+hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights& w, float* Y, const NextProj& nx,
+                        int M, int D, int F, hipStream_t s);
 extern int g_ffn_mb_override;
+extern int g_fuse_layer;
+extern int g_attn_impl;
+extern int g_dbg;
+extern int g_attn_qg;
 
-// attention over qkv (M x 3d row-major, [q|k|v]); tokens >= n_own take K/V from the
-// (H,L,hd) tables kt/vt instead of the sample's own rows. out: (M x d).
-hipError_t launch_attention(const float* qkv, const float* kt, const float* vt, float* out, int B, int L, int H,
-                            int hd, int n_own, hipStream_t s);
-// table[h][l][e] (l < n) <- kv[l][which*d + h*hd + e]  from a (L x 2d) [k|v] buffer of sample 0
-hipError_t launch_kv_store(const float* kv, int ldkv, float* kt, float* vt, int L, int H, int hd, int n, hipStream_t s);
+// Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]
+// laid out (B, H, L, hd) -- each (sample, head) slice contiguous, the layout of the K/V tables.
+hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, float* out0, float* out1, float* out2,
+                            int M, int nreg, int D, int L, int H, int hd, hipStream_t s);
+// attention over head-major q, k, v (B,H,L,hd); tokens >= n_own take K/V from the
+// (H,L,hd) tables kt/vt instead of the sample's own rows. out: (M x d) row-major.
+hipError_t launch_attention(const float* q, const float* k, const float* v, const float* kt, const float* vt,
+                            float* out, int B, int L, int H, int hd, int n_own, hipStream_t s);
+// table[h][l][:] (l < n) <- sample 0's head-major K/V rows
+hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt, int L, int H, int hd, int n,
+                           hipStream_t s);
 // crf[l][:] <- h[l][:] for sample 0 is a plain D2D copy (done with hipMemcpyAsync)
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);

@@ -9,13 +9,19 @@
 
 namespace ffd {
 
+// Stage a 64-row tile (contiguous 64*D floats of a row-major (M x D) matrix) into LDS with
+// coalesced float4 loads; rows >= M are zero.
 template <int D>
 __device__ __forceinline__ void load_x_tile(const float* __restrict__ X, float* xs, int m0, int M) {
   constexpr int S = lds_stride(D);
-  for (int idx = threadIdx.x; idx < 64 * D; idx += blockDim.x) {
-    int r = idx / D, k = idx - r * D;
-    int m = m0 + r;
-    xs[r * S + k] = (m < M) ? X[(size_t)m * D + k] : 0.f;
+  const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)m0 * D);
+  const int rows_valid = min(64, M - m0);
+  for (int i4 = threadIdx.x; i4 < 64 * D / 4; i4 += blockDim.x) {
+    const int r = (4 * i4) / D, k = 4 * i4 - r * D;
+    const float4 v = (r < rows_valid) ? X4[i4] : float4{0.f, 0.f, 0.f, 0.f};
+    float2* dst = reinterpret_cast<float2*>(&xs[r * S + k]);  // S even: 8-byte aligned
+    dst[0] = float2{v.x, v.y};
+    dst[1] = float2{v.z, v.w};
   }
 }
 
@@ -73,6 +79,103 @@ __global__ __launch_bounds__(256) void k_linear(const float* __restrict__ X, con
   }
 }
 
+// Head-major projection (Q / K / V): column n = reg*d + h*hd + e of row m = b*L + l goes to
+// out[reg][((b*H + h)*L + l)*hd + e].  32-row tiles; the (32 x N) result is staged in LDS in
+// destination order -- [(reg, h)][row][e] -- so every (reg, h) slice leaves as one contiguous
+// 32*hd-float run (rows of a sample are contiguous in the head-major layout).
+template <int D>
+__global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                   const float* __restrict__ bias, float* __restrict__ out0,
+                                                   float* __restrict__ out1, float* __restrict__ out2, int M, int N,
+                                                   int L, int H, int hd, unsigned hd_inv) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  constexpr int R = 32;
+  __shared__ __align__(16) float xs[R * S];
+  __shared__ __align__(16) float stage[R * 3 * D];
+  __shared__ unsigned rowbase[R];
+  const int m0 = blockIdx.x * R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NT = cdiv(N, 16);
+  const float4* Wq = reinterpret_cast<const float4*>(Wp);
+  float4 wq[G], wn[G];
+  if (wave < NT) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = Wq[((size_t)wave * G + g) * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)m0 * D);
+    const int rows_valid = min(R, M - m0);
+    for (int i4 = threadIdx.x; i4 < R * D / 4; i4 += 256) {
+      const int r = (4 * i4) / D, k = 4 * i4 - r * D;
+      const float4 v = (r < rows_valid) ? X4[i4] : float4{0.f, 0.f, 0.f, 0.f};
+      float2* dst = reinterpret_cast<float2*>(&xs[r * S + k]);
+      dst[0] = float2{v.x, v.y};
+      dst[1] = float2{v.z, v.w};
+    }
+    if (threadIdx.x < R) {
+      const int m = m0 + threadIdx.x;
+      const int b = m / L, l = m - b * L;
+      rowbase[threadIdx.x] = (m < M) ? (unsigned)((b * H * L + l) * hd) : 0xFFFFFFFFu;
+    }
+  }
+  __syncthreads();
+  float xf[2][KS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
+  for (int nt = wave; nt < NT; nt += 4) {
+    if (nt + 4 < NT) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) wn[g] = Wq[((size_t)(nt + 4) * G + g) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 q = wq[s >> 2];
+      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+      acc[0] = mfma16(a, xf[0][s], acc[0]);
+      acc[1] = mfma16(a, xf[1][s], acc[1]);
+    }
+    const int n = 16 * nt + 4 * (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int nn = n + r;
+      if (nn < N) {
+        const int rh = (int)(((unsigned)nn * hd_inv) >> 16), e = nn - rh * hd;  // rh = reg*H + h  (d = H*hd)
+        const float bv = bias[nn];
+        stage[(rh * R + (lane & 15)) * hd + e] = acc[0][r] + bv;
+        stage[(rh * R + 16 + (lane & 15)) * hd + e] = acc[1][r] + bv;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = wn[g];
+  }
+  __syncthreads();
+  // copy-out: one (reg*H + h, row) pair per thread iteration = hd contiguous floats
+  const int npairs = (N / hd) * R;
+  for (int id = threadIdx.x; id < npairs; id += 256) {
+    const int rh = id >> 5, row = id & 31;
+    const unsigned rb = rowbase[row];
+    if (rb == 0xFFFFFFFFu) continue;
+    const int reg = rh >= 2 * H ? 2 : rh >= H ? 1 : 0;
+    const int h = rh - reg * H;
+    float* dst = (reg == 0 ? out0 : reg == 1 ? out1 : out2) + rb + (unsigned)(h * L * hd);
+    const float* src = &stage[(rh * R + row) * hd];
+    if ((hd & 1) == 0) {
+      for (int e = 0; e < hd; e += 2) *reinterpret_cast<float2*>(dst + e) = *reinterpret_cast<const float2*>(src + e);
+    } else {
+      for (int e = 0; e < hd; ++e) dst[e] = src[e];
+    }
+  }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__ X, const float* __restrict__ Wp,
                                                        const float* __restrict__ bias, const float* __restrict__ R,
@@ -82,33 +185,39 @@ __global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
   constexpr int CT = cdiv(D, 16);
-  __shared__ float xs[64 * S];
+  __shared__ __align__(16) float xs[64 * S];
+  __shared__ __align__(16) float rs[64 * S];
   const int m0 = blockIdx.x * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // every weight fragment up front (CT*G float4 per lane): latency hides under the tile staging
+  const float4* Wq = reinterpret_cast<const float4*>(Wp);
+  float4 wq[CT][G];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[ct][g] = Wq[((size_t)ct * G + g) * 64 + lane];
+  __builtin_amdgcn_sched_barrier(0);
   load_x_tile<D>(X, xs, m0, M);
+  load_x_tile<D>(R, rs, m0, M);
   __syncthreads();
   float xf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) xf[s] = xs[(16 * wave + (lane & 15)) * S + 4 * s + (lane >> 4)];
 
-  const float4* Wq = reinterpret_cast<const float4*>(Wp);
   f32x4 acc[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    float4 wq[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) wq[g] = Wq[((size_t)ct * G + g) * 64 + lane];
     acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float4 q = wq[s >> 2];
+      const float4 q = wq[ct][s >> 2];
       const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
       acc[ct] = mfma16(a, xf[s], acc[ct]);
     }
   }
   // epilogue: lane holds row m, columns n = 16 ct + 4 (lane>>4) + r
   const int m = m0 + 16 * wave + (lane & 15);
-  const int mc = m < M ? m : M - 1;
+  const float* rrow = &rs[(16 * wave + (lane & 15)) * S];
   float v[CT][4];
   float sum = 0.f;
 #pragma unroll
@@ -117,7 +226,7 @@ __global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__
     for (int r = 0; r < 4; ++r) {
       const int n = 16 * ct + 4 * (lane >> 4) + r;
       if (n < D) {
-        v[ct][r] = acc[ct][r] + bias[n] + R[(size_t)mc * D + n];
+        v[ct][r] = acc[ct][r] + bias[n] + rrow[n];
         sum += v[ct][r];
       } else {
         v[ct][r] = 0.f;
@@ -163,6 +272,23 @@ hipError_t launch_linear(const float* X, const float* Wp, const float* bias, flo
     case 24: hipLaunchKernelGGL(k_linear<24>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
     case 60: hipLaunchKernelGGL(k_linear<60>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
     case 72: hipLaunchKernelGGL(k_linear<72>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+int g_dbg = 0;
+
+hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, float* out0, float* out1, float* out2,
+                            int M, int nreg, int D, int L, int H, int hd, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  const int N = nreg * D;
+  const unsigned hd_inv = (65536u + hd - 1) / hd;  // exact floor(c / hd) for c < 2^16 / hd
+  dim3 grid(cdiv(M, 32)), block(256);
+  switch (D) {
+    case 24: hipLaunchKernelGGL(k_linear_hm<24>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
+    case 60: hipLaunchKernelGGL(k_linear_hm<60>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
+    case 72: hipLaunchKernelGGL(k_linear_hm<72>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
