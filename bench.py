@@ -208,14 +208,22 @@ def main() -> None:
         flops_step = lib.ffd_flops_per_sample_step(ctx.handle, 0) * B
         out["achieved_tflops_whole_step"] = flops_step / (ms_per_step * 1e-3) / 1e12
         if args.workload != "nasa_lstm":
-            ms = C.c_float()
-            N.check(lib.ffd_bench_ffn(ctx.handle, B, 50, C.byref(ms), stream), ctx.handle, "ffd_bench_ffn")
+            # dominant kernel, timed in situ: HIP event pairs around every k_ffn_ln launch of 20 more
+            # sampling steps on the launch stream (same quantity rocprofv3 --kernel-trace reports)
+            NLy = model.num_layers
+            N.check(lib.ffd_ffn_timing_begin(ctx.handle, 20 * NLy), ctx.handle, "ffd_ffn_timing_begin")
+            run_steps(model, sampler, X, ts_c, n_total, step_size, 1, 20, use_cache, stream, offset)
+            ms, cnt = C.c_float(), C.c_int()
+            N.check(lib.ffd_ffn_timing_end(ctx.handle, C.byref(ms), C.byref(cnt)), ctx.handle, "ffd_ffn_timing_end")
             fl = lib.ffd_ffn_flops_per_launch(ctx.handle, B)
             ach = fl / (ms.value * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_ffn_ln<72,8> (fused FFN + residual + LayerNorm2)", "bound": "mfma",
-                               "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            iso = C.c_float()
+            N.check(lib.ffd_bench_ffn(ctx.handle, B, 50, C.byref(iso), stream), ctx.handle, "ffd_bench_ffn")
+            out["roofline"] = {"kernel": "k_ffn_ln<72,4> (fused FFN: linear1 + relu + linear2 + residual + LayerNorm2)",
+                               "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                               "flops_per_launch": fl, "ms_per_launch": ms.value}
+                               "flops_per_launch": fl, "ms_per_launch": ms.value, "launches_timed": cnt.value,
+                               "ms_per_launch_back_to_back": iso.value}
             if not use_cache and world == 1:
                 # cache-on / cache-off ratio at the same batch (BASELINE configs[2]), 200 steps each
                 def timed(uc):

@@ -73,6 +73,8 @@ SIGNATURES = {
                                    C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "ffd_flops_per_sample_step": (C.c_double, [_P, C.c_int]),
     "ffd_ffn_flops_per_launch": (C.c_double, [_P, C.c_int]),
+    "ffd_ffn_timing_begin": (C.c_int, [_P, C.c_int]),
+    "ffd_ffn_timing_end": (C.c_int, [_P, _F, C.POINTER(C.c_int)]),
     "ffd_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
 }

@@ -28,7 +28,7 @@ struct LstmLayer {
 };
 
 struct LayerPacked {
-  float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p;
+  float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
 };
 
 __global__ void k_add_vec(const float* a, const float* b, float* o, int n) {
@@ -65,8 +65,10 @@ struct ffd_ctx {
   int temb_cap = 0;
   std::vector<float> ts_host;
   long weight_epoch = 0, temb_epoch = -1;
-  float* bench_x = nullptr;
-  int bench_B = 0;
+  // in-situ timing of the dominant kernel (ffd_ffn_timing_*)
+  bool time_ffn = false;
+  std::vector<hipEvent_t> ev;  // pairs (start, stop)
+  size_t ev_used = 0;
   // cache
   bool cache_enabled = false;
   ffd_cache_cfg ccfg{5, 10};
@@ -115,6 +117,10 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "ffn_mb")) {
     if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return FFD_ERR_INVALID;
     g_ffn_mb_override = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rem")) {
+    g_ffn_rem = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "bench_kernel")) {  // what ffd_bench_ffn times: 0 k_ffn_ln, 1 k_layer, 2 k_layer + next QKV
@@ -240,6 +246,7 @@ void ffd_destroy(ffd_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
   for (void* p : ctx->owned) (void)hipFree(p);
+  for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
   delete ctx;
 }
 
@@ -335,6 +342,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if ((rc = dev_alloc(ctx, &pk.out_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w2p, w2pack_floats(d, F)))) return rc;
+        if ((rc = dev_alloc(ctx, &pk.w2r, w2rem_floats(d, F)))) return rc;
       }
       float* in_w = W(pre + "self_attn.in_proj_weight");
       HIPCHECK(launch_pack_dweight(in_w, pk.in_wp, 3 * d, d, s));
@@ -343,6 +351,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(W(pre + "self_attn.out_proj.weight"), pk.out_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
       HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
+      HIPCHECK(launch_pack_w2rem(W(pre + "linear2.weight"), pk.w2r, d, F, s));
       LayerWeights& lw = ctx->layers[i];
       lw.in_w = in_w;
       lw.in_b = W(pre + "self_attn.in_proj_bias");
@@ -360,6 +369,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       lw.out_wp = pk.out_wp;
       lw.w1p = pk.w1p;
       lw.w2p = pk.w2p;
+      lw.w2r = pk.w2r;
     }
   } else {
     const bool first = ctx->lstm.empty();
@@ -480,7 +490,13 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
       alt = t;
     } else {
       HIPCHECK(launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+      const bool timed = ctx->time_ffn && ctx->ev_used + 2 <= ctx->ev.size();
+      if (timed) HIPCHECK(hipEventRecord(ctx->ev[ctx->ev_used], s));
       HIPCHECK(launch_ffn_ln(alt, w, cur, M, d, F, s));
+      if (timed) {
+        HIPCHECK(hipEventRecord(ctx->ev[ctx->ev_used + 1], s));
+        ctx->ev_used += 2;
+      }
     }
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
@@ -729,6 +745,39 @@ double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B) {
   if (!ctx) return 0.0;
   const ffd_model_desc& m = ctx->desc;
   return 4.0 * (double)B * m.max_len * m.d_model * m.dim_feedforward;
+}
+
+int ffd_ffn_timing_begin(ffd_ctx* ctx, int max_launches) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (max_launches < 1 || max_launches > 100000) return ctx->fail(FFD_ERR_INVALID, "max_launches=%d", max_launches);
+  HIPCHECK(hipSetDevice(ctx->device));
+  while (ctx->ev.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    HIPCHECK(hipEventCreate(&e));
+    ctx->ev.push_back(e);
+  }
+  ctx->ev_used = 0;
+  ctx->time_ffn = true;
+  return FFD_OK;
+}
+
+int ffd_ffn_timing_end(ffd_ctx* ctx, float* avg_ms_out, int* launches_out) {
+  if (!ctx) return FFD_ERR_INVALID;
+  ctx->time_ffn = false;
+  if (!avg_ms_out || !launches_out) return ctx->fail(FFD_ERR_INVALID, "null output");
+  HIPCHECK(hipSetDevice(ctx->device));
+  double tot = 0.0;
+  const size_t n = ctx->ev_used / 2;
+  for (size_t i = 0; i < n; ++i) {
+    HIPCHECK(hipEventSynchronize(ctx->ev[2 * i + 1]));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+    tot += ms;
+  }
+  *avg_ms_out = n ? (float)(tot / n) : 0.f;
+  *launches_out = (int)n;
+  ctx->ev_used = 0;
+  return FFD_OK;
 }
 
 int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {

@@ -41,6 +41,31 @@ __global__ void k_pack_w2(const float* __restrict__ W2, float* __restrict__ W2p,
   }
 }
 
+__global__ void k_pack_w2rem(const float* __restrict__ W2, float* __restrict__ W2r, int D, int F) {
+  const int NG = w2rem_groups(D);
+  const int c0 = 16 * (D / 16);
+  const size_t total = (size_t)(F / 16) * NG * 64 * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int r = i & 3;
+    int lane = (i >> 2) & 63;
+    size_t rest = i >> 8;
+    int g = rest % NG;
+    int fc = rest / NG;
+    int c = c0 + 4 * g + (lane & 3);
+    int f = 16 * fc + 4 * (lane >> 4) + r;
+    W2r[i] = W2[(size_t)c * F + f];
+  }
+}
+
+hipError_t launch_pack_w2rem(const float* W2, float* W2r, int D, int F, hipStream_t s) {
+  if (w2rem_groups(D) == 0) return hipSuccess;
+  size_t total = (size_t)(F / 16) * w2rem_groups(D) * 64 * 4;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_pack_w2rem, dim3(blocks), dim3(256), 0, s, W2, W2r, D, F);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s) {
   size_t total = dpack_floats(N, D);
   int blocks = (int)((total + 255) / 256);

@@ -23,16 +23,25 @@
 
 namespace ffd {
 
-template <int D, int MB>
+// REM = true: the d % 16 remainder rows of GEMM2 (8 of 72) run on v_mfma_f32_4x4x1_16b_f32
+// (8 cycles per instruction) instead of a zero-padded 16-row tile: block b = lane>>2 multiplies
+// A[lane 4b+i] by B[lane 4b+j], and with a GEMM1 accumulator register as B that is
+//   W2[c0 + 4g + i][16 fc + 4q + r] * H^T[16 fc + 4q + r][16 mb + 4 mq + j],  q = lane>>4, mq = (lane>>2)&3,
+// so each lane-quarter q accumulates the partial sum over its hidden units and the four
+// partials are added with two cross-lane xor-adds once per tile.
+template <int D, int MB, bool REM>
 __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* __restrict__ X, const float* __restrict__ W1p,
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
-                                                  const float* __restrict__ b2, const float* __restrict__ gam,
-                                                  const float* __restrict__ bet, float* __restrict__ Y, int M,
-                                                  int F) {
+                                                  const float* __restrict__ W2r, const float* __restrict__ b2,
+                                                  const float* __restrict__ gam, const float* __restrict__ bet,
+                                                  float* __restrict__ Y, int M, int F) {
   constexpr int S = lds_stride(D);
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
-  constexpr int CT = cdiv(D, 16);
+  constexpr int CTP = cdiv(D, 16);                       // tiles in the packed w2 image
+  constexpr int NG = REM ? w2rem_groups(D) : 0;           // 4-row remainder groups on the 4x4x1 path
+  constexpr int CT = (NG > 0) ? D / 16 : cdiv(D, 16);     // 16-row tiles on the 16x16x4 path
+  constexpr int NGA = NG > 0 ? NG : 1;
   constexpr int R = 16 * MB;
   constexpr int S2 = ((D + 3) / 4) * 4 + 4;  // partial-sum row stride (16-byte aligned rows)
   __shared__ __align__(16) float xs[R * S];
@@ -65,12 +74,18 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 yrem[NGA][MB];
+#pragma unroll
+  for (int g = 0; g < NGA; ++g)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- main loop over this wave's quarter of F, 16 hidden units per chunk ----
   const int nchunk = F / 64;  // chunks per wave
   const int fc0 = wave * nchunk;
   const float4* W1q = reinterpret_cast<const float4*>(W1p) + (size_t)fc0 * G * 64 + lane;
-  const float4* W2q = reinterpret_cast<const float4*>(W2p) + (size_t)fc0 * CT * 64 + lane;
+  const float4* W2q = reinterpret_cast<const float4*>(W2p) + (size_t)fc0 * CTP * 64 + lane;
+  const float4* W2rq = reinterpret_cast<const float4*>(W2r) + (size_t)fc0 * NGA * 64 + lane;
   const float4* b1q = reinterpret_cast<const float4*>(b1 + 16 * fc0) + (lane >> 4);
 
   // Software pipeline with single register buffers: W1(ci+1) streams in while GEMM2(ci)
@@ -78,7 +93,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   // runs.  Each load set therefore has >= 18*MB MFMAs (>= 4.6k cycles at MB = 8) to land
   // from L2.  The sched_barriers pin the issue points: left alone, hipcc sinks each load
   // next to its first use and exposes a vmcnt(0) stall every ~16 MFMAs.
-  float4 w1[G], w2[CT], bv;
+  float4 w1[G], w2[CT], w2r[NGA], bv;
   auto load_w1 = [&](int c) {
 #pragma unroll
     for (int g = 0; g < G; ++g) w1[g] = W1q[((size_t)c * G + g) * 64];
@@ -86,7 +101,11 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   };
   auto load_w2 = [&](int c) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) w2[ct] = W2q[((size_t)c * CT + ct) * 64];
+    for (int ct = 0; ct < CT; ++ct) w2[ct] = W2q[((size_t)c * CTP + ct) * 64];
+    if (NG > 0) {
+#pragma unroll
+      for (int g = 0; g < NGA; ++g) w2r[g] = W2rq[((size_t)c * NGA + g) * 64];
+    }
   };
   load_w1(0);
   load_w2(0);
@@ -121,6 +140,18 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
       }
+    if (NG > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < NGA; ++g) {
+          const float4 q = w2r[g];
+          const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb)
+            yrem[g][mb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, h[mb][r], yrem[g][mb], 0, 0, 0);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     load_w2(nx);
     __builtin_amdgcn_sched_barrier(0);
@@ -129,6 +160,21 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   // ---- deterministic cross-wave reduction: wave 0 adds its partial into the LDS X tile
   // (= the residual), waves 1..3 park theirs in red[]; one barrier; every thread then sums
   // x + p0 (already in xs) + p1 + p2 + p3 + b2 in that fixed order.
+  if (NG > 0) {
+    // add the four lane-quarter partials: afterwards every quarter holds the full sums
+    // yrem[g][mb][i] = Y^T[c0 + 4g + i][16 mb + (lane & 15)]
+#pragma unroll
+    for (int g = 0; g < NGA; ++g)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = yrem[g][mb][i];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          yrem[g][mb][i] = v;
+        }
+  }
   if (wave == 0) {
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -139,6 +185,18 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
           const int c = 16 * ct + 4 * (lane >> 4) + r;
           if (c < D) xs[(16 * mb + (lane & 15)) * S + c] += yacc[ct][mb][r];
         }
+    if (NG > 0 && (lane >> 4) < NGA) {  // quarter q handles remainder group g = q
+      const int g = lane >> 4;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v = 0.f;
+#pragma unroll
+          for (int gg = 0; gg < NGA; ++gg) v = (gg == g) ? yrem[gg][mb][i] : v;
+          xs[(16 * mb + (lane & 15)) * S + 16 * CT + 4 * g + i] += v;
+        }
+    }
   } else {
     float* rw = red + (size_t)(wave - 1) * R * S2;
 #pragma unroll
@@ -150,6 +208,17 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
           *reinterpret_cast<float4*>(&rw[(16 * mb + (lane & 15)) * S2 + c]) =
               float4{yacc[ct][mb][0], yacc[ct][mb][1], yacc[ct][mb][2], yacc[ct][mb][3]};
       }
+    if (NG > 0 && (lane >> 4) < NGA) {
+      const int g = lane >> 4;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int gg = 0; gg < NGA; ++gg)
+          if (gg == g) v = float4{yrem[gg][mb][0], yrem[gg][mb][1], yrem[gg][mb][2], yrem[gg][mb][3]};
+        *reinterpret_cast<float4*>(&rw[(16 * mb + (lane & 15)) * S2 + 16 * CT + 4 * g]) = v;
+      }
+    }
   }
   __syncthreads();
 
@@ -197,6 +266,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   }
 }
 
+int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
 int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
 
 template <int D>
@@ -209,9 +279,15 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
   dim3 block(256);
-#define FFD_LAUNCH_FFN(MBV)                                                                                     \
-  hipLaunchKernelGGL((k_ffn_ln<D, MBV>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p, w.b2, w.n2w, \
-                     w.n2b, Y, M, F)
+#define FFD_LAUNCH_FFN(MBV)                                                                                       \
+  do {                                                                                                            \
+    if (g_ffn_rem && MBV == 4 && w2rem_groups(D) > 0)                                                                       \
+      hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,   \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F);                                                     \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,  \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F);                                                     \
+  } while (0)
   switch (mb) {
     case 8: FFD_LAUNCH_FFN(8); break;
     case 4: FFD_LAUNCH_FFN(4); break;

@@ -48,6 +48,7 @@ struct LayerWeights {
   const float *out_wp;  // dpack (d x d)
   const float *w1p;     // dpack (F x d)
   const float *w2p;     // w2pack
+  const float *w2r;     // w2rem (remainder rows d % 16 of linear2.weight, 4x4x1 MFMA A-operand order)
 };
 
 // The next layer's input projection, fused as the epilogue of k_layer (nreg = 0: none,
@@ -61,6 +62,13 @@ struct NextProj {
 
 hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s);
 hipError_t launch_pack_w2(const float* W2, float* W2p, int D, int F, hipStream_t s);
+// "w2rem": rows c >= 16*(D/16) of linear2.weight (D x F), in groups of 4, as the A operand of
+// v_mfma_f32_4x4x1_16b_f32 with a GEMM1 accumulator register r as B (block b = lane>>2 pairs
+// A[lane 4b+i] with B[lane 4b+j]):  [fc = F/16][g][lane 64][r 4]
+//   = W2[16*(D/16) + 4 g + (lane & 3)][16 fc + 4 (lane >> 4) + r]
+constexpr __host__ __device__ int w2rem_groups(int D) { return (D % 16) / 4; }
+constexpr __host__ __device__ size_t w2rem_floats(int D, int F) { return (size_t)(F / 16) * (w2rem_groups(D) ? w2rem_groups(D) : 1) * 64 * 4; }
+hipError_t launch_pack_w2rem(const float* W2, float* W2r, int D, int F, hipStream_t s);
 hipError_t launch_renorm_rows(float* W, int rows, int D, float max_norm, hipStream_t s);
 
 // temb[n][d] = dense(gamma(t_n)) for n timesteps (transformer.py:77-91)
@@ -97,6 +105,7 @@ hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M,
 hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights& w, float* Y, const NextProj& nx,
                         int M, int D, int F, hipStream_t s);
 extern int g_ffn_mb_override;
+extern int g_ffn_rem;
 extern int g_fuse_layer;
 extern int g_attn_impl;
 extern int g_dbg;

@@ -206,6 +206,12 @@ int ffd_tune(const char* key, int value);
  * the fused FFN kernel per launch at batch B. */
 double ffd_flops_per_sample_step(const ffd_ctx* ctx, int cache_hit);
 double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B);
+/* In-situ timing of the dominant kernel (fused FFN + LN2): between _begin and _end every
+ * k_ffn_ln launch issued by forward / sample calls on this context is bracketed by a HIP
+ * event pair on the launch stream (up to max_launches); _end synchronises and returns the
+ * mean duration.  For bench.py's roofline; adds two event records per timed launch. */
+int ffd_ffn_timing_begin(ffd_ctx* ctx, int max_launches);
+int ffd_ffn_timing_end(ffd_ctx* ctx, float* avg_ms_out, int* launches_out);
 /* Time `iters` launches of the dominant kernel (fused FFN+LN2 of layer 0) at batch B
  * on `stream` with HIP events; returns average milliseconds per launch in *ms_out.
  * Synchronous (benchmark helper only). */

@@ -10,14 +10,16 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "ecg"
 model, sch, sd = bench.build_model(dev, wl)
 ctx = model._ctx(); lib = ctx.lib
 fl = lib.ffd_ffn_flops_per_launch(ctx.handle, B)
-res = {mb: [] for mb in (8, 4, 2, 1)}
+res = {(mb, rem): [] for mb in (8, 4, 2, 1) for rem in (0, 1)}
 for rnd in range(5):
-    for mb in res:
+    for (mb, rem) in res:
         lib.ffd_tune(b"ffn_mb", mb)
+        lib.ffd_tune(b"ffn_rem", rem)
         ms = C.c_float()
         N.check(lib.ffd_bench_ffn(ctx.handle, B, 20, C.byref(ms), None), ctx.handle)
-        res[mb].append(ms.value)
+        res[(mb, rem)].append(ms.value)
 lib.ffd_tune(b"ffn_mb", 0)
+lib.ffd_tune(b"ffn_rem", 1)
 for mb, v in res.items():
     med = statistics.median(v)
-    print(f"MB={mb}: median {med*1e3:.1f} us  min {min(v)*1e3:.1f} us  -> {fl/med/1e9:.1f} TFLOP/s ({fl/med/1e9/157.3*100:.1f}% of fp32 MFMA peak)")
+    print(f"MB,rem={mb}: median {med*1e3:.1f} us  min {min(v)*1e3:.1f} us  -> {fl/med/1e9:.1f} TFLOP/s ({fl/med/1e9/157.3*100:.1f}% of fp32 MFMA peak)")
