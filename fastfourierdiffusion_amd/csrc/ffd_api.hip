@@ -143,7 +143,7 @@ int ffd_tune(const char* key, int value) {
     return FFD_OK;
   }
   if (!strcmp(key, "attn_impl")) {
-    if (value != 0 && value != 1) return FFD_ERR_INVALID;
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_attn_impl = value;
     return FFD_OK;
   }

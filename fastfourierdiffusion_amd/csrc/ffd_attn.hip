@@ -12,6 +12,8 @@
 // E2-CRF modes (cached_transformer.py:237-305): keys l < n_own come from the
 // sample's own K/V projections (qkv buffer), keys l >= n_own from the shared
 // (H, L, hd) tables -- n_own = L is the standard layer, 0 the pure-cache step.
+#include <type_traits>
+
 #include "ffd_internal.h"
 
 namespace ffd {
@@ -315,7 +317,164 @@ static hipError_t launch_attn_mfma_hd(const float* q, const float* k, const floa
   return launch_attn_mfma_t<HD, 2>(q, k, v, kt, vt, out, B, L, H, n_own, s);
 }
 
-int g_attn_impl = 0;  // 0 = hybrid MFMA/VALU (default), 1 = pure VALU (ffd_tune "attn_impl")
+// ---------------------------------------------------------------------------
+// v3 (experiment, ffd_tune attn_impl=2): both products on the 16-block 4x4x1 matrix instruction.
+// Measured: the instruction issues every 11.1 cycles (8 independent chains) with 40 cycles of
+// dependent latency (tools/probes/bench_mfma4x4.hip), i.e. 0.6 cycles per (query,key) pair at
+// best -- slower than the hybrid kernel's VALU-bound 0.42; kept for reference (113 us vs 98 us).
+//
+// v_mfma_f32_4x4x1_16b_f32 computes, for each of 16 lane blocks b, the 4x4 outer product
+// D_b[i][j] += A[lane 4*bsel+i] * B[lane 4b+j]; with cbsz = 4 every block takes its A values
+// from block `abid`.  With one query per lane (B operand = that lane's own scalar):
+//   scores : A = K^T register (lane l holds K[k0+l][e]), abid = g  ->  D[i] = q_e * K[k0+4g+i][e]
+//            summed over e by chaining: 4 scores (keys k0+4g..+3) per lane, hd instructions
+//   P V    : A = V register (lane l holds V[k0+(l>>2)][l&3]), abid = kk, B = p[kk]
+//            -> D[i] += p * V[k0+kk][i] : the lane's 4 output dims, one instruction per key
+//            (a second register / instruction covers dims 4..7)
+// so neither product pads to a 16- or 32-wide tile (hd = 6: 6 + 2 = 8 cycles-8 instructions
+// per 4 / 1 keys), the P values never leave the lane, and the online-softmax state is one
+// (m, l, O[hd]) per lane.  K^T / V rows of the (sample, head) are staged once per workgroup
+// (ceil(L/64) waves = all query blocks of that head) and read with coalesced ds_read_b32.
+// ---------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(512) void k_attention_v3(const float* __restrict__ qg, const float* __restrict__ kg,
+                                                      const float* __restrict__ vg, const float* __restrict__ kt,
+                                                      const float* __restrict__ vt, float* __restrict__ out, int B,
+                                                      int L, int H, int n_own) {
+  constexpr bool HI = HD > 4;
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = blockIdx.x;  // (b, h)
+  const int b = pair / H, h = pair - b * H;
+  const int d = H * HD;
+  const int SB = (L + 63) >> 6;  // 64-key super-blocks
+  const int Lp = SB * 64;
+  float* kts = lds;                  // K^T [HD][Lp]
+  float* vlo = kts + HD * Lp;        // V dims 0..3   [Lp][4]
+  float* vhi = vlo + 4 * Lp;         // V dims 4..7   [Lp][4]  (zero beyond HD)
+
+  for (int idx = threadIdx.x; idx < Lp * (HD + 8); idx += blockDim.x) lds[idx] = 0.f;
+  __syncthreads();
+  const size_t slice = (size_t)pair * L * HD;
+  {
+    const float* kown = kg + slice;
+    const float* vown = vg + slice;
+    const float* ktab = kt ? kt + (size_t)h * L * HD : kown;
+    const float* vtab = vt ? vt + (size_t)h * L * HD : vown;
+    const int own_elems = n_own * HD;
+    for (int idx = threadIdx.x; idx < L * HD; idx += blockDim.x) {
+      const int j = idx / HD, e = idx - j * HD;
+      const bool own = idx < own_elems;
+      const float kx = (own ? kown : ktab)[idx];
+      const float vx = (own ? vown : vtab)[idx];
+      kts[e * Lp + j] = kx;
+      if (e < 4) vlo[4 * j + e] = vx;
+      else vhi[4 * j + (e - 4)] = vx;
+    }
+  }
+  __syncthreads();
+
+  const int q0 = 64 * wave;
+  if (q0 >= L) return;
+  const int qi = min(q0 + lane, L - 1);
+  const float c = 1.4426950408889634f / sqrtf((float)HD);
+  float q[HD];
+#pragma unroll
+  for (int e = 0; e < HD; ++e) q[e] = qg[slice + (size_t)qi * HD + e] * c;
+  float m = -INFINITY, lsum = 0.f;
+  f32x4 olo = {0.f, 0.f, 0.f, 0.f}, ohi = {0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int sb = 0; sb < SB; ++sb) {
+    const int k0 = 64 * sb;
+    float kr[HD];
+#pragma unroll
+    for (int e = 0; e < HD; ++e) kr[e] = kts[e * Lp + k0 + lane];
+    float vl[4], vh[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      vl[g] = vlo[4 * (k0 + 16 * g) + lane];
+      vh[g] = HI ? vhi[4 * (k0 + 16 * g) + lane] : 0.f;
+    }
+    const bool ragged = k0 + 64 > L;
+    static_for<0, 4>([&](auto gq_c) {
+      constexpr int gq = decltype(gq_c)::value;
+      // ---- 16 scores per lane: keys k0 + 16 gq + 4 gi + i
+      f32x4 sc[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) sc[gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < HD; ++e) {
+        sc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(kr[e], q[e], sc[0], 4, 4 * gq + 0, 0);
+        sc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(kr[e], q[e], sc[1], 4, 4 * gq + 1, 0);
+        sc[2] = __builtin_amdgcn_mfma_f32_4x4x1f32(kr[e], q[e], sc[2], 4, 4 * gq + 2, 0);
+        sc[3] = __builtin_amdgcn_mfma_f32_4x4x1f32(kr[e], q[e], sc[3], 4, 4 * gq + 3, 0);
+      }
+      if (ragged) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (k0 + 16 * gq + 4 * gi + i >= L) sc[gi][i] = -INFINITY;
+      }
+      // ---- online softmax on the 16 scores
+      float bm = sc[0][0];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bm = fmaxf(bm, sc[gi][i]);
+      const float mnew = fmaxf(m, bm);
+      const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+      const float corr = __builtin_amdgcn_exp2f(m - msafe);
+      m = mnew;
+      float l = lsum * corr;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) olo[i] *= corr, ohi[i] *= corr;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = __builtin_amdgcn_exp2f(sc[gi][i] - msafe);
+          sc[gi][i] = p;
+          l += p;
+        }
+      lsum = l;
+      // ---- O += p_k * V[k] : one instruction per key (two when hd > 4)
+      static_for<0, 16>([&](auto kk_c) {
+        constexpr int kk = decltype(kk_c)::value;
+        const float p = sc[kk >> 2][kk & 3];
+        olo = __builtin_amdgcn_mfma_f32_4x4x1f32(vl[gq], p, olo, 4, kk, 0);
+        if (HI) ohi = __builtin_amdgcn_mfma_f32_4x4x1f32(vh[gq], p, ohi, 4, kk, 0);
+      });
+    });
+  }
+
+  if (q0 + lane < L) {
+    const float inv = 1.0f / lsum;
+    float* orow = out + ((size_t)b * L + q0 + lane) * d + h * HD;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) orow[e] = (e < 4 ? olo[e] : ohi[e - 4]) * inv;
+  }
+}
+
+template <int HD>
+static hipError_t launch_attn_v3(const float* q, const float* k, const float* v, const float* kt, const float* vt,
+                                 float* out, int B, int L, int H, int n_own, hipStream_t s) {
+  const int SB = (L + 63) / 64;
+  const size_t lds = (size_t)SB * 64 * (HD + 8) * sizeof(float);
+  hipLaunchKernelGGL((k_attention_v3<HD>), dim3(B * H), dim3(64 * SB), lds, s, q, k, v, kt, vt, out, B, L, H, n_own);
+  return hipGetLastError();
+}
+
+int g_attn_impl = 0;  // 0 = 32x32x2 QK^T + VALU softmax/PV (default, fastest measured), 1 = all VALU, 2 = 4x4x1-MFMA products
 
 template <int HD, int QPL>
 static hipError_t launch_attn_t(const float* q, const float* k, const float* v, const float* kt, const float* vt,
@@ -350,6 +509,15 @@ static hipError_t launch_attn_hd(const float* qkv, const float* k, const float* 
 hipError_t launch_attention(const float* qkv, const float* k, const float* v, const float* kt, const float* vt,
                             float* out, int B, int L, int H, int hd, int n_own, hipStream_t s) {
   if (B <= 0) return hipSuccess;
+  if (g_attn_impl == 2) {
+    switch (hd) {
+      case 4: return launch_attn_v3<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 5: return launch_attn_v3<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 6: return launch_attn_v3<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      case 8: return launch_attn_v3<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (g_attn_impl == 0) {
     switch (hd) {
       case 4: return launch_attn_mfma_hd<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);

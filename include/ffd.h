@@ -197,7 +197,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
 /* Process-wide tuning knob for experiments (results never change, only tiling):
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8  -- rows/16 per workgroup of the fused FFN;
  *   "fuse_layer" = -1 (auto) | 0 | 1 -- out-proj+LN1+FFN+LN2+next-QKV in one launch (k_layer);
- *   "attn_impl" = 0 (MFMA QK^T + VALU softmax/PV, default) | 1 (all-VALU kernel). */
+ *   "attn_impl" = 0 (32x32x2-MFMA QK^T + VALU softmax/PV, default) | 1 (all VALU) | 2 (4x4x1-MFMA products). */
 int ffd_tune(const char* key, int value);
 
 /* ---- introspection for benchmarks --------------------------------------- */

@@ -176,7 +176,7 @@ def test_philox_noise_statistics_and_shard_invariance(ffd):
 
 
 # -------------------------------------------------------------- models -----
-@pytest.fixture(params=["auto", "fused", "valu_attn"])
+@pytest.fixture(params=["auto", "fused", "valu_attn", "mfma4x4_attn"])
 def variant(request, ffd):
     """Kernel variants that must all meet the same parity bar: default heuristics, the
     fused k_layer path forced on (small batches otherwise take the unfused kernels), and
@@ -188,9 +188,10 @@ def variant(request, ffd):
         assert lib.ffd_tune(b"fuse_layer", 1) == 0
     elif request.param == "valu_attn":
         assert lib.ffd_tune(b"attn_impl", 1) == 0
-        assert lib.ffd_tune(b"fuse_layer", 0) == 0
+    elif request.param == "mfma4x4_attn":
+        assert lib.ffd_tune(b"attn_impl", 2) == 0
     yield request.param
-    lib.ffd_tune(b"fuse_layer", -1)
+    lib.ffd_tune(b"fuse_layer", 0)
     lib.ffd_tune(b"attn_impl", 0)
 
 
