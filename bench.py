@@ -219,9 +219,15 @@ def main() -> None:
             ach = fl / (ms.value * 1e-3) / 1e12
             iso = C.c_float()
             N.check(lib.ffd_bench_ffn(ctx.handle, B, 50, C.byref(iso), stream), ctx.handle, "ffd_bench_ffn")
+            traffic = None  # HBM bytes per launch from the committed PMC passes (cannot be collected in-process)
+            tpath = os.path.join(ROOT, "profiles", "r01_ffn_traffic.json")
+            if args.workload == "ecg" and B == 512 and os.path.exists(tpath):
+                traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
             out["roofline"] = {"kernel": "k_ffn_ln<72,4> (fused FFN: linear1 + relu + linear2 + residual + LayerNorm2)",
                                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                               "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                                               "profiles/r01_ffn_traffic.json",
                                "flops_per_launch": fl, "ms_per_launch": ms.value, "launches_timed": cnt.value,
                                "ms_per_launch_back_to_back": iso.value}
             if not use_cache and world == 1:
