@@ -31,6 +31,7 @@ _MIRROR = {
     "fdiff.schedulers.sde": "fastfourierdiffusion_amd.schedulers.sde",
     "fdiff.utils.caching": "fastfourierdiffusion_amd.utils.caching",
     "fdiff.utils.fourier": "fastfourierdiffusion_amd.utils.fourier",
+    "fdiff.utils.fresca": "fastfourierdiffusion_amd.utils.fresca",
     "fdiff.utils.dataclasses": "fastfourierdiffusion_amd.utils.dataclasses",
 }
 

@@ -34,6 +34,11 @@ class SdeDesc(C.Structure):
     _fields_ = [("sde", C.c_int32), ("reserved", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
 
 
+class FrescaCfg(C.Structure):
+    _fields_ = [("low_scale", C.c_float), ("high_scale", C.c_float), ("cutoff_ratio", C.c_double),
+                ("strategy", C.c_int32), ("num_steps", C.c_int32)]
+
+
 class CacheCfg(C.Structure):
     _fields_ = [("K", C.c_int32), ("R", C.c_int32)]
 
@@ -64,6 +69,9 @@ SIGNATURES = {
     "ffd_prior": (C.c_int, [C.POINTER(SdeDesc), _P, _P, _P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_dft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_idft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ffd_fresca": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double, C.c_int, _P]),
+    "ffd_fresca_enable": (C.c_int, [_P, C.POINTER(FrescaCfg)]),
+    "ffd_fresca_disable": (C.c_int, [_P]),
     "ffd_cache_enable": (C.c_int, [_P, C.POINTER(CacheCfg)]),
     "ffd_cache_disable": (C.c_int, [_P]),
     "ffd_cache_reset": (C.c_int, [_P]),

@@ -69,6 +69,11 @@ struct ffd_ctx {
   bool time_ffn = false;
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
   size_t ev_used = 0;
+  // FreSca (sampler-level)
+  bool fresca_on = false;
+  ffd_fresca_cfg fcfg{};
+  float *score2 = nullptr, *fwork = nullptr;
+  int fwork_B = 0;
   // cache
   bool cache_enabled = false;
   ffd_cache_cfg ccfg{5, 10};
@@ -614,6 +619,31 @@ int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream) {
   return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
 }
 
+int ffd_fresca(const float* in, float* out, float* work, int B, int L, int C, float low_scale, float high_scale,
+               double cutoff_ratio, int strategy, void* stream) {
+  if (!in || !out || in == out || B < 1 || L < 2 || C < 1) return FFD_ERR_INVALID;
+  if (strategy != FFD_FRESCA_SPATIAL && strategy != FFD_FRESCA_ENERGY) return FFD_ERR_INVALID;  // fresca.py:60 ValueError
+  if (strategy == FFD_FRESCA_ENERGY && !work) return FFD_ERR_INVALID;
+  hipError_t e = launch_fresca(in, out, work, B, L, C, low_scale, high_scale, cutoff_ratio, strategy, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+int ffd_fresca_enable(ffd_ctx* ctx, const ffd_fresca_cfg* cfg) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (!cfg) return ctx->fail(FFD_ERR_INVALID, "null fresca config");
+  if (cfg->strategy != FFD_FRESCA_SPATIAL && cfg->strategy != FFD_FRESCA_ENERGY)
+    return ctx->fail(FFD_ERR_INVALID, "unknown cutoff strategy %d", cfg->strategy);
+  ctx->fcfg = *cfg;
+  ctx->fresca_on = true;
+  return FFD_OK;
+}
+
+int ffd_fresca_disable(ffd_ctx* ctx) {
+  if (!ctx) return FFD_ERR_INVALID;
+  ctx->fresca_on = false;
+  return FFD_OK;
+}
+
 // ---------------------------------------------------------------------------
 // cache lifecycle
 // ---------------------------------------------------------------------------
@@ -690,6 +720,11 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   const ffd_model_desc& m = ctx->desc;
   const int d = m.d_model;
   hipStream_t s = (hipStream_t)stream;
+  if (ctx->fresca_on && B > ctx->fwork_B) {
+    if ((rc = dev_alloc(ctx, &ctx->score2, (size_t)B * m.max_len * m.n_channels))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->fwork, (size_t)B * m.n_channels * (m.max_len / 2 + 1) + 4))) return rc;
+    ctx->fwork_B = B;
+  }
   // All time embeddings of the trajectory in one launch: t is shared by the batch
   // (sampler.py:59-60).  The table is kept across batches and only rebuilt (with one
   // stream sync) when the timestep grid or the weights changed.
@@ -721,7 +756,18 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
     if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, ctx->score, nullptr, B, n_rec, s))) return rc;
     if (use_cache) ctx->stats.current_step = i;  // sampler.py:73-74 (Q4)
     const double t = (double)timesteps[i];
-    HIPCHECK(launch_sde_step(x, ctx->score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
+    const float* score = ctx->score;
+    if (ctx->fresca_on) {  // sampler.py:79-93 -> fresca.py:220-268
+      const ffd_fresca_cfg& f = ctx->fcfg;
+      double h = (double)f.high_scale;
+      if (f.num_steps > 0 && h > 1.0) h = (1.0 - t / (double)f.num_steps) * (h - 1.0) + 1.0;
+      if (!((double)f.low_scale == 1.0 && h == 1.0)) {  // fresca.py:137-138 early exit
+        HIPCHECK(launch_fresca(ctx->score, ctx->score2, ctx->fwork, B, m.max_len, m.n_channels, f.low_scale, (float)h,
+                               f.cutoff_ratio, f.strategy, s));
+        score = ctx->score2;
+      }
+    }
+    HIPCHECK(launch_sde_step(x, score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
                              sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B, m.max_len,
                              m.n_channels, s));
   }

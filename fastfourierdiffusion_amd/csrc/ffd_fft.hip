@@ -30,6 +30,46 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// All Stockham passes of a length-L complex FFT over cg channels (channel-innermost LDS image
+// of stride CG); returns the buffer holding the result.  W holds the (possibly conjugated) twiddles.
+__device__ __forceinline__ float2* stockham(float2* x, float2* y, const float2* W, const FftPlan& plan, int L, int CG,
+                                            int cg) {
+  int n = L, s = 1;
+  for (int ps = 0; ps < plan.npass; ++ps) {
+    const int R = plan.radix[ps];
+    const int m = n / R;
+    const int LR = L / R;
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      const int i = idx / cg, cc = idx - i * cg;
+      const int q = i % s;
+      const int t = i / s;
+      const int k = t % R;
+      const int p = t / R;
+      const float2* xp = x + (size_t)(q + s * p) * CG + cc;
+      const int stride = s * m * CG;
+      float2 acc = xp[0];
+      int tw = 0;  // (j*k mod R) * L/R
+      for (int j = 1; j < R; ++j) {
+        tw += k * LR;
+        if (tw >= L) tw -= L;
+        float2 a = xp[(size_t)j * stride];
+        float2 w = W[tw];
+        acc.x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc.x));
+        acc.y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc.y));
+      }
+      acc = cmul(acc, W[p * k * s]);
+      y[(size_t)i * CG + cc] = acc;
+    }
+    __syncthreads();
+    float2* tmp = x;
+    x = y;
+    y = tmp;
+    n = m;
+    s *= R;
+  }
+  return x;
+}
+
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float* __restrict__ out,
                                              const float2* __restrict__ Wg, FftPlan plan, int L, int C, int CG,
@@ -69,41 +109,7 @@ __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float
   }
   __syncthreads();
 
-  float2* x = bufA;
-  float2* y = bufB;
-  int n = L, s = 1;
-  for (int ps = 0; ps < plan.npass; ++ps) {
-    const int R = plan.radix[ps];
-    const int m = n / R;
-    const int LR = L / R;
-    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
-      const int i = idx / cg, cc = idx - i * cg;
-      const int q = i % s;
-      const int t = i / s;
-      const int k = t % R;
-      const int p = t / R;
-      const float2* xp = x + (size_t)(q + s * p) * CG + cc;
-      const int stride = s * m * CG;
-      float2 acc = xp[0];
-      int tw = 0;  // (j*k mod R) * L/R
-      for (int j = 1; j < R; ++j) {
-        tw += k * LR;
-        if (tw >= L) tw -= L;
-        float2 a = xp[(size_t)j * stride];
-        float2 w = W[tw];
-        acc.x = fmaf(a.x, w.x, fmaf(-a.y, w.y, acc.x));
-        acc.y = fmaf(a.x, w.y, fmaf(a.y, w.x, acc.y));
-      }
-      acc = cmul(acc, W[p * k * s]);
-      y[(size_t)i * CG + cc] = acc;
-    }
-    __syncthreads();
-    float2* tmp = x;
-    x = y;
-    y = tmp;
-    n = m;
-    s *= R;
-  }
+  float2* x = stockham(bufA, bufB, W, plan, L, CG, cg);
 
   if (!INVERSE) {
     for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
@@ -120,6 +126,109 @@ __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// FreSca (fresca.py:111-268): score <- irfft( (l*low + h*high) (.) rfft(score) ), low = [k <= Rc].
+//   k_fresca_spectrum : per sample, partial[b][k] = sum_c |X[b,k,c]|   (ortho rfft, k = 0..L/2)
+//   k_fresca_cutoff   : spec[k] = mean_{b,c}; Rc = first k with cumsum >= r0 * sum  (fresca.py:46-58)
+//   k_fresca_apply    : FFT -> scale each bin by l or h -> inverse FFT, all in LDS, Rc read on device
+// The energy cutoff is a batch-wide statistic, reduced in a fixed order (deterministic).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fresca_spectrum(const float* __restrict__ in, float* __restrict__ partial,
+                                                         const float2* __restrict__ Wg, FftPlan plan, int L, int C,
+                                                         int CG, float scale) {
+  extern __shared__ __align__(16) float2 sm[];
+  float2* W = sm;
+  float2* bufA = sm + L;
+  float2* bufB = bufA + L * CG;
+  const int b = blockIdx.x;
+  const int c0 = blockIdx.y * CG;
+  const int cg = min(CG, C - c0);
+  const float* src = in + (size_t)b * L * C;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) W[i] = Wg[i];
+  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+    const int l = idx / cg, cc = idx - l * cg;
+    bufA[l * CG + cc] = make_float2(src[(size_t)l * C + c0 + cc], 0.f);
+  }
+  __syncthreads();
+  float2* x = stockham(bufA, bufB, W, plan, L, CG, cg);
+  const int nf = L / 2 + 1;
+  for (int k = threadIdx.x; k < nf; k += blockDim.x) {
+    float acc = 0.f;
+    for (int c = 0; c < cg; ++c) {
+      const float2 v = x[k * CG + c];
+      acc += sqrtf(fmaf(v.x * scale, v.x * scale, (v.y * scale) * (v.y * scale)));
+    }
+    partial[((size_t)b * gridDim.y + blockIdx.y) * nf + k] = acc;
+  }
+}
+
+__global__ void k_fresca_cutoff(const float* __restrict__ partial, int* __restrict__ rc_out, int B, int nrows, int nf,
+                                int C, double cutoff_ratio) {
+  extern __shared__ float spec[];
+  for (int k = threadIdx.x; k < nf; k += blockDim.x) {
+    float acc = 0.f;
+    for (int b = 0; b < nrows; ++b) acc += partial[(size_t)b * nf + k];
+    spec[k] = acc / (float)(B * C);  // mean over batch and channels (fresca.py:150)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float etot = 0.f;
+    for (int k = 0; k < nf; ++k) etot += spec[k];  // torch.abs(freq_spectrum).sum() in fp32
+    const double thr = cutoff_ratio * (double)etot;
+    double cum = 0.0;  // python float accumulation of .item() values
+    int rc = 0;
+    for (int k = 0; k < nf; ++k) {
+      cum += (double)spec[k];
+      if (cum >= thr) {
+        rc = k;
+        break;
+      }
+    }
+    *rc_out = rc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fresca_apply(const float* __restrict__ in, float* __restrict__ out,
+                                                      const float2* __restrict__ Wg, FftPlan plan, int L, int C,
+                                                      int CG, const int* __restrict__ rc_dev, float rc_host,
+                                                      float low, float high, float scale2) {
+  extern __shared__ __align__(16) float2 sm[];
+  float2* W = sm;
+  float2* bufA = sm + L;
+  float2* bufB = bufA + L * CG;
+  const int b = blockIdx.x;
+  const int c0 = blockIdx.y * CG;
+  const int cg = min(CG, C - c0);
+  const float* src = in + (size_t)b * L * C;
+  float* dst = out + (size_t)b * L * C;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) W[i] = Wg[i];
+  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+    const int l = idx / cg, cc = idx - l * cg;
+    bufA[l * CG + cc] = make_float2(src[(size_t)l * C + c0 + cc], 0.f);
+  }
+  __syncthreads();
+  float2* x = stockham(bufA, bufB, W, plan, L, CG, cg);
+  // low-pass set: k <= Rc (energy: integer index from the cutoff kernel; spatial: Rc = r0 * n_freq)
+  const float rc = rc_dev ? (float)(*rc_dev) : rc_host;
+  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+    const int k = idx / cg, cc = idx - k * cg;
+    const int kk = (k <= L / 2) ? k : L - k;  // Hermitian partner shares its bin's factor
+    const float f = ((float)kk <= rc) ? low : high;
+    float2 v = x[k * CG + cc];
+    x[k * CG + cc] = make_float2(v.x * f, v.y * f);
+  }
+  for (int i = threadIdx.x; i < L; i += blockDim.x) W[i].y = -W[i].y;  // conjugate twiddles: inverse transform
+  __syncthreads();
+  float2* other = (x == bufA) ? bufB : bufA;
+  float2* y = stockham(x, other, W, plan, L, CG, cg);
+  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+    const int l = idx / cg, cc = idx - l * cg;
+    dst[(size_t)l * C + c0 + cc] = y[l * CG + cc].x * scale2;
+  }
+}
+
+static FftPlan make_plan(int L);
 
 static FftPlan make_plan(int L) {
   FftPlan p{};
@@ -188,6 +297,38 @@ hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inve
     hipLaunchKernelGGL(k_fft<true>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
   else
     hipLaunchKernelGGL(k_fft<false>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
+  return hipGetLastError();
+}
+
+hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,
+                         double cutoff_ratio, int strategy, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (L < 2 || C < 1 || L > 4096) return hipErrorInvalidValue;
+  const float2* W = nullptr;
+  hipError_t e = get_twiddles(L, &W);
+  if (e != hipSuccess) return e;
+  FftPlan plan = make_plan(L);
+  int CG = C;
+  while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
+  const size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  const int NGc = cdiv(C, CG);
+  const int nf = L / 2 + 1;
+  const float sc = (float)(1.0 / sqrt((double)L));
+  const int* rc_dev = nullptr;
+  float rc_host = 0.f;
+  if (strategy == 1) {  // energy (fresca.py:46-58)
+    float* partial = work;
+    int* rc = reinterpret_cast<int*>(work + (size_t)B * NGc * nf);
+    hipLaunchKernelGGL(k_fresca_spectrum, dim3(B, NGc), dim3(256), lds, s, in, partial, W, plan, L, C, CG, sc);
+    hipLaunchKernelGGL(k_fresca_cutoff, dim3(1), dim3(256), nf * sizeof(float), s, partial, rc, B, B * NGc, nf, C,
+                       cutoff_ratio);
+    rc_dev = rc;
+  } else {  // spatial (fresca.py:40-43): Rc = r0 * n_freq, compared in fp32 like the reference's k tensor
+    rc_host = (float)(cutoff_ratio * (double)nf);
+  }
+  hipLaunchKernelGGL(k_fresca_apply, dim3(B, NGc), dim3(256), lds, s, in, out, W, plan, L, C, CG, rc_dev, rc_host, low,
+                     high, sc * sc);
   return hipGetLastError();
 }
 

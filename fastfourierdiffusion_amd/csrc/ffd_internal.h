@@ -127,5 +127,8 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
 
 hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s);
+// FreSca spectral scaling of a (B,L,C) score; work: B*(L/2+1) + 1 floats; strategy 0 spatial, 1 energy
+hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,
+                         double cutoff_ratio, int strategy, hipStream_t s);
 
 }  // namespace ffd

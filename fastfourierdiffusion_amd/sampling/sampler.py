@@ -52,10 +52,8 @@ class DiffusionSampler:
         self.fresca_high_scale = fresca_high_scale
         self.fresca_cutoff_ratio = fresca_cutoff_ratio
         self.fresca_cutoff_strategy = fresca_cutoff_strategy
-        if use_fresca:
-            raise NotImplementedError(
-                "use_fresca=True: FreSca per-step spectral scaling is the first 'next' row of the scope table "
-                "(SURVEY 8(f)); not built yet")
+        if fresca_cutoff_strategy not in ("spatial", "energy"):
+            self.fresca_cutoff_strategy = "spatial"  # sampler.py:83-85 maps anything but "energy" to "spatial"
         # extensions (not in the reference signature)
         assert rng in ("torch", "philox")
         self.rng = rng
@@ -92,6 +90,13 @@ class DiffusionSampler:
                 self.score_model.cache.current_step = step
         else:
             score = self.score_model(batch)
+        if self.use_fresca:  # sampler.py:79-93
+            from ..utils.fresca import apply_fresca_to_score
+
+            score = apply_fresca_to_score(score, low_scale=self.fresca_low_scale, high_scale=self.fresca_high_scale,
+                                          cutoff_ratio=self.fresca_cutoff_ratio,
+                                          cutoff_strategy="energy" if self.fresca_cutoff_strategy == "energy" else "spatial",
+                                          timestep=t_lo, num_steps=getattr(self, "_num_diffusion_steps", None))
         output = self.noise_scheduler.step(model_output=score, timestep=timesteps[0].item(), sample=X)
         X_prev = output.prev_sample
         assert isinstance(X_prev, torch.Tensor)
@@ -113,6 +118,14 @@ class DiffusionSampler:
 
         model = self.score_model
         ctx = model._ctx()
+        if self.use_fresca:
+            cfg = N.FrescaCfg(float(self.fresca_low_scale), float(self.fresca_high_scale),
+                              float(self.fresca_cutoff_ratio),
+                              1 if self.fresca_cutoff_strategy == "energy" else 0,
+                              int(getattr(self, "_num_diffusion_steps", 0) or 0))
+            N.check(ctx.lib.ffd_fresca_enable(ctx.handle, C.byref(cfg)), ctx.handle, "ffd_fresca_enable")
+        else:
+            N.check(ctx.lib.ffd_fresca_disable(ctx.handle), ctx.handle, "ffd_fresca_disable")
         device = model.device
         stream = N.current_stream_ptr(device)
         all_samples = []

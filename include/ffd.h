@@ -166,6 +166,28 @@ int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G,
 int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream);
 int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream);
 
+/* FreSca spectral scaling (fdiff.utils.fresca.frequency_scale / apply_fresca_to_score,
+ * fresca.py:111-268, 3-D case): out = irfft((low*[k<=Rc] + high*[k>Rc]) (.) rfft(in)) along dim 1.
+ * strategy 0 "spatial": Rc = cutoff_ratio * (L/2+1); 1 "energy": Rc = first k whose cumulative
+ * batch-mean |X_k| reaches cutoff_ratio * total (fresca.py:46-58; a batch-wide statistic, reduced
+ * on the device in a fixed order -- no host sync).  `work` = B*C*(L/2+1) + 4 floats of scratch.
+ * Context-free; in != out.  low == high == 1 is the caller's early exit (fresca.py:137-138). */
+enum { FFD_FRESCA_SPATIAL = 0, FFD_FRESCA_ENERGY = 1 };
+int ffd_fresca(const float* in, float* out, float* work, int B, int L, int C, float low_scale, float high_scale,
+               double cutoff_ratio, int strategy, void* stream);
+
+/* DiffusionSampler(use_fresca=True, ...) (sampler.py:21-26,79-93): apply FreSca to every score
+ * inside ffd_sample_batch, with the reference's time-dependent high scale
+ * h(t) = (1 - t/num_steps)*(h-1) + 1 for h > 1 (fresca.py:247-257; num_steps <= 0: static h). */
+typedef struct {
+  float low_scale, high_scale;
+  double cutoff_ratio;
+  int32_t strategy;   /* FFD_FRESCA_* */
+  int32_t num_steps;  /* the sampler's _num_diffusion_steps, or 0 when unset */
+} ffd_fresca_cfg;
+int ffd_fresca_enable(ffd_ctx* ctx, const ffd_fresca_cfg* cfg);
+int ffd_fresca_disable(ffd_ctx* ctx);
+
 /* ---- the sampling loop -------------------------------------------------- */
 
 /* E2CRFCache lifecycle used by DiffusionSampler (sampler.py:37-39,151-153):

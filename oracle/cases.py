@@ -60,6 +60,12 @@ TRAJ_CASES = [
          num_samples=5, N=6, use_cache=True, cache_kwargs={}, wseed=42, zseed=54),
     dict(name="traj_small_vp_cache_R100", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=2,
          num_samples=4, N=120, use_cache=True, cache_kwargs={"K": 3, "R": 100}, wseed=42, zseed=55),
+    dict(name="traj_small_fresca", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=3, num_samples=3, N=8,
+         use_cache=False, wseed=42, zseed=62, fresca=dict(low_scale=1.0, high_scale=1.5, cutoff_ratio=0.5,
+                                                          cutoff_strategy="energy")),
+    dict(name="traj_small_fresca_cache_spatial", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=2,
+         num_samples=2, N=8, use_cache=True, cache_kwargs={}, wseed=42, zseed=63,
+         fresca=dict(low_scale=0.9, high_scale=1.2, cutoff_ratio=0.4, cutoff_strategy="spatial")),
     dict(name="traj_small_time", **_SMALL, sde="vp", sde_kwargs=VP, fourier=False, B=2, num_samples=2, N=8,
          use_cache=False, wseed=42, zseed=56),
     dict(name="traj_reftest_vp", **_REFTEST, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2, N=10,
@@ -77,6 +83,19 @@ TRAJ_CASES = [
     dict(name="traj_nasa_lstm_20", **_NASA_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2,
          N=20, use_cache=False, wseed=45, zseed=61),
 ]
+
+# FreSca on a raw score tensor: (name, L, C, B, seed, low, high, cutoff_ratio, strategy, timestep, num_steps)
+FRESCA_CASES = [
+    ("ecg_energy", 187, 1, 6, 71, 1.0, 1.5, 0.5, "energy", None, None),
+    ("ecg_energy_dyn", 187, 1, 6, 72, 1.0, 1.5, 0.5, "energy", 0.73, 100),
+    ("ecg_spatial", 187, 1, 4, 73, 0.8, 1.3, 0.25, "spatial", None, None),
+    ("nasa_energy", 251, 4, 3, 74, 0.9, 2.0, 0.7, "energy", 0.2, 1000),
+    ("even_energy", 100, 3, 5, 75, 1.2, 0.7, 0.3, "energy", None, None),
+    ("syn_spatial", 512, 8, 2, 76, 1.0, 1.5, 0.5, "spatial", 1.0, 1000),
+    ("syn_energy", 512, 8, 2, 77, 1.1, 1.4, 0.9, "energy", None, None),
+    ("identity", 50, 3, 2, 78, 1.0, 1.0, 0.5, "energy", None, None),
+]
+FRESCA_DEFAULT = dict(low_scale=1.0, high_scale=1.5, cutoff_ratio=0.5, cutoff_strategy="energy")  # benchmark_cache.py:63-68
 
 # (K, R, L, steps)
 _STEPS = [0, 1, 2, 5, 10, 99, 100, 150, 200, 300, 499, 500, 501, 999, 1000, 1500]

@@ -140,6 +140,66 @@ def idft(xt: Tensor) -> Tensor:
 
 
 # --------------------------------------------------------------------------
+# F3 : FreSca spectral scaling of the score   (src/fdiff/utils/fresca.py)
+# --------------------------------------------------------------------------
+
+
+def fresca_high_scale(high_scale: float, timestep: Optional[float], num_steps: Optional[int]) -> float:
+    """apply_fresca_to_score, fresca.py:247-257 (python double arithmetic)."""
+    if timestep is not None and num_steps is not None:
+        t_normalized = timestep / num_steps if num_steps > 0 else 0.0
+        if high_scale > 1.0:
+            return (1.0 - t_normalized) * (high_scale - 1.0) + 1.0
+    return high_scale
+
+
+def fresca_cutoff(spec: Tensor, cutoff_ratio: float) -> int:
+    """create_frequency_masks, 1-D energy branch, fresca.py:46-58: spec is the fp32
+    batch/channel mean of |X_k|; Etot an fp32 sum; the running sum a python double."""
+    etot = torch.abs(spec).sum()
+    rc, cum = 0, 0.0
+    for i in range(spec.shape[0]):
+        cum += torch.abs(spec[i]).item()
+        if cum >= cutoff_ratio * etot.item():
+            rc = i
+            break
+    return rc
+
+
+def fresca(score: Tensor, low_scale: float = 1.0, high_scale: float = 1.0, cutoff_ratio: float = 0.5,
+           cutoff_strategy: str = "energy", timestep: Optional[float] = None,
+           num_steps: Optional[int] = None) -> Tensor:
+    """apply_fresca_to_score -> frequency_scale (3-D case), fresca.py:111-217, 220-268.
+    rfft / irfft restated as explicit fp64 DFT sums (see dft/idft above)."""
+    h = fresca_high_scale(high_scale, timestep, num_steps)
+    if low_scale == 1.0 and h == 1.0:
+        return score
+    B, L, C = score.shape
+    nf = L // 2 + 1
+    cr, ci = _dft_mats(L)  # (nf, L): cos/sqrtL, -sin/sqrtL
+    xd = score.detach().to(torch.float64).numpy()
+    re = np.einsum("kn,bnc->bkc", cr, xd)
+    im = np.einsum("kn,bnc->bkc", ci, xd)
+    k = torch.arange(nf).float()
+    if cutoff_strategy == "spatial":
+        low = (k <= cutoff_ratio * nf).float().numpy()  # fresca.py:40-43
+    elif cutoff_strategy == "energy":
+        mag = torch.from_numpy(np.sqrt(re * re + im * im).astype(np.float32))
+        rc = fresca_cutoff(mag.mean(dim=(0, 2)), cutoff_ratio)  # fresca.py:150-153
+        low = (k <= rc).float().numpy()
+    else:
+        raise ValueError(f"Unknown cutoff_strategy: {cutoff_strategy}")
+    f = (np.float32(low_scale) * low + np.float32(h) * (1.0 - low)).astype(np.float64)[None, :, None]
+    re, im = re * f, im * f
+    w = np.full(nf, 2.0)
+    w[0] = 1.0
+    if L % 2 == 0:
+        w[-1] = 1.0
+    out = np.einsum("kn,bkc->bnc", cr * w[:, None], re) + np.einsum("kn,bkc->bnc", ci * w[:, None], im)
+    return torch.from_numpy(out.astype(np.float32))
+
+
+# --------------------------------------------------------------------------
 # M2 / M3 : positional + time encoders     (src/fdiff/models/transformer.py)
 # --------------------------------------------------------------------------
 
@@ -386,7 +446,8 @@ def lstm_score_forward(x: Tensor, t: Tensor, sd: Dict[str, Tensor], num_layers: 
 def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, num_layers: int,
            n_head: int, sde: str, sde_kwargs: Dict[str, float], fourier_noise_scaling: bool,
            num_samples: int, batch_size: int, num_steps: int, noise: Iterable[Tensor],
-           use_cache: bool = False, K: int = 5, R: int = 10, eps: float = 1e-5) -> Tensor:
+           use_cache: bool = False, K: int = 5, R: int = 10, eps: float = 1e-5,
+           fresca_kwargs: Optional[Dict] = None) -> Tensor:
     """DiffusionSampler.sample, sampler.py:105-215, with the N(0,1) draws taken
     from ``noise`` in call order (one (B,L,C) tensor for the prior of each
     batch, then one per step) instead of torch's CPU generator.
@@ -415,6 +476,8 @@ def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, n
                 score = lstm_score_forward(x, t, sd, num_layers)
             else:
                 score = score_forward(x, t, sd, num_layers, n_head, table if use_cache else None, rec)
+            if fresca_kwargs is not None:  # sampler.py:79-93
+                score = fresca(score, timestep=t_val, num_steps=num_steps, **fresca_kwargs)
             z = next(noise)
             if sde == "vp":
                 x = vp_step(x, score, z, t_val, G, step_size, **sde_kwargs)

@@ -185,13 +185,27 @@ def main() -> None:
         B, L, C, N = c["B"], c["L"], c["C"], c["N"]
         nb = max(1, c["num_samples"] // B)
         stream = synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"])
+        fk = c.get("fresca")
+        fres = {} if fk is None else dict(use_fresca=True, fresca_low_scale=fk["low_scale"],
+                                          fresca_high_scale=fk["high_scale"], fresca_cutoff_ratio=fk["cutoff_ratio"],
+                                          fresca_cutoff_strategy=fk["cutoff_strategy"])
         sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
-                                      cache_kwargs=dict(c.get("cache_kwargs", {})))
+                                      cache_kwargs=dict(c.get("cache_kwargs", {})), **fres)
         with injected_noise(stream):
             out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
         g[c["name"]] = out.numpy()
         print(c["name"], out.shape, float(out.abs().max()))
     np.savez_compressed(os.path.join(OUT, "g7_traj.npz"), **g)
+
+    # ---- G6b: FreSca on raw score tensors ---------------------------------
+    from fdiff.utils.fresca import apply_fresca_to_score
+    g = {}
+    for (name, L, C, B, seed, lo, hi, ratio, strat, tstep, nsteps) in cases.FRESCA_CASES:
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
+        y = apply_fresca_to_score(x, low_scale=lo, high_scale=hi, cutoff_ratio=ratio, cutoff_strategy=strat,
+                                  timestep=tstep, num_steps=nsteps)
+        g[name] = y.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g6_fresca.npz"), **g)
 
     # ---- G9: gate schedule ------------------------------------------------
     g = {}

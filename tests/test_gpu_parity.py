@@ -119,6 +119,36 @@ def test_fft_host_tensor_roundtrip_and_full_size(ffd):
     assert torch.allclose(e_t, e_f, rtol=1e-5)
 
 
+# ------------------------------------------------------------- FreSca ------
+@pytest.mark.parametrize("case", cases.FRESCA_CASES, ids=lambda c: c[0])
+def test_fresca_golden(ffd, golden, case):
+    from fastfourierdiffusion_amd.utils.fresca import apply_fresca_to_score
+
+    name, L, C, B, seed, lo, hi, ratio, strat, tstep, nsteps = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed))).cuda()
+    y = apply_fresca_to_score(x, low_scale=lo, high_scale=hi, cutoff_ratio=ratio, cutoff_strategy=strat,
+                              timestep=tstep, num_steps=nsteps)
+    assert rel_err(y.cpu(), golden["g6_fresca"][name]) < TOL_OP
+    if lo == 1.0 and hi == 1.0:
+        assert y is x  # fresca.py:137-138 early exit returns the input itself
+
+
+def test_fresca_full_batch_properties(ffd):
+    """B=512 ECG batch: l = h = s is a pure scaling (linearity of rfft/irfft), and the energy
+    cutoff is a batch statistic: permuting the samples permutes the output."""
+    from fastfourierdiffusion_amd.utils.fresca import frequency_scale
+
+    x = torch.randn(512, 187, 1, device="cuda")
+    y = frequency_scale(x, low_scale=0.75, high_scale=0.75, cutoff_ratio=0.5, cutoff_strategy="energy")
+    assert torch.allclose(y, 0.75 * x, atol=2e-6)
+    perm = torch.randperm(512, device="cuda")
+    a = frequency_scale(x, 1.0, 1.5, 0.5, "energy")
+    b = frequency_scale(x[perm], 1.0, 1.5, 0.5, "energy")
+    assert rel_err(b.cpu(), a[perm].cpu()) < 1e-6
+    with pytest.raises(ValueError):
+        frequency_scale(x, 1.0, 1.5, 0.5, "radial")
+
+
 # ---------------------------------------------------------------- SDE ------
 @pytest.mark.parametrize("c", cases.STEP_CASES, ids=lambda c: c["name"])
 def test_step_golden(ffd, golden, c):
@@ -285,8 +315,12 @@ def test_traj_golden(ffd, golden, c, variant):
     m, sch = make_model(ffd, c)
     B, L, C, N = c["B"], c["L"], c["C"], c["N"]
     nb = max(1, c["num_samples"] // B)
+    fk = c.get("fresca")
+    fres = {} if fk is None else dict(use_fresca=True, fresca_low_scale=fk["low_scale"],
+                                      fresca_high_scale=fk["high_scale"], fresca_cutoff_ratio=fk["cutoff_ratio"],
+                                      fresca_cutoff_strategy=fk["cutoff_strategy"])
     sampler = DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
-                               cache_kwargs=dict(c.get("cache_kwargs", {})), z_chunk_steps=64)
+                               cache_kwargs=dict(c.get("cache_kwargs", {})), z_chunk_steps=64, **fres)
     sampler.inject_noise(synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
     # the golden trajectory was generated on the timestep grid stored in g2_tables; torch.linspace
     # on this host may differ from it in the last ulp (vector width), so pin the grid.

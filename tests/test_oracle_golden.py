@@ -119,6 +119,14 @@ def test_model_golden(golden, c):
             np.array([table.recompute_count, table.cache_hit_count]), g[f"{name}_cstats"])
 
 
+@pytest.mark.parametrize("case", cases.FRESCA_CASES, ids=lambda c: c[0])
+def test_fresca_golden(golden, case):
+    name, L, C, B, seed, lo, hi, ratio, strat, tstep, nsteps = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
+    y = O.fresca(x, lo, hi, ratio, strat, tstep, nsteps)
+    assert rel_err(y, golden["g6_fresca"][name]) < TOL_KERNEL
+
+
 _FAST_TRAJ = [c for c in cases.TRAJ_CASES if c["N"] * (c["d"] // 24) <= 400]
 _SLOW_TRAJ = [c for c in cases.TRAJ_CASES if c not in _FAST_TRAJ]
 
@@ -132,7 +140,7 @@ def _run_traj(golden, c):
     out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"],
                    sde=c["sde"], sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"],
                    num_samples=c["num_samples"], batch_size=B, num_steps=N, noise=noise,
-                   use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10))
+                   use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10), fresca_kwargs=c.get("fresca"))
     ref = golden["g7_traj"][c["name"]]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
