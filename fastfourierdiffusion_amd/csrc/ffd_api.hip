@@ -619,6 +619,24 @@ int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream) {
   return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
 }
 
+int ffd_positional_encoding(const float* x, float* weight, float* out, int B, int L, int D, float max_norm,
+                            void* stream) {
+  if (!x || !weight || !out || B < 1 || L < 1 || D < 1) return FFD_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  // nn.Embedding(max_norm) renormalises the looked-up rows in place at every forward (transformer.py:13-15,26)
+  if (max_norm > 0.f && launch_renorm_rows_once(weight, L, D, max_norm, s) != hipSuccess) return FFD_ERR_HIP;
+  return launch_add_table(x, weight, nullptr, out, B, L, D, s) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
+int ffd_time_encoding(const float* x, const float* timesteps, const float* W, const float* dense_w,
+                      const float* dense_b, float* temb_work, float* out, int B, int L, int D, void* stream) {
+  if (!x || !timesteps || !W || !dense_w || !dense_b || !temb_work || !out || B < 1 || L < 1 || D < 1)
+    return FFD_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_time_embed(timesteps, 0.f, B, W, dense_w, dense_b, temb_work, D, s) != hipSuccess) return FFD_ERR_HIP;
+  return launch_add_table(x, nullptr, temb_work, out, B, L, D, s) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
 int ffd_fresca(const float* in, float* out, float* work, int B, int L, int C, float low_scale, float high_scale,
                double cutoff_ratio, int strategy, void* stream) {
   if (!in || !out || in == out || B < 1 || L < 2 || C < 1) return FFD_ERR_INVALID;

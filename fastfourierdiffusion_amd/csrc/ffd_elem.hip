@@ -174,6 +174,51 @@ hipError_t launch_embed(const float* X, const float* We, const float* be, const 
 }
 
 // ---------------------------------------------------------------------------
+// standalone encoders: out[b,l,:] = x[b,l,:] + rowtab[l,:] (positional) or + battab[b,:] (time)
+// ---------------------------------------------------------------------------
+__global__ void k_add_table(const float* __restrict__ x, const float* __restrict__ rowtab,
+                            const float* __restrict__ battab, float* __restrict__ out, unsigned total, int L, int D) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned row = i / (unsigned)D;
+    const int j = (int)(i - row * (unsigned)D);
+    const unsigned b = row / (unsigned)L;
+    const int l = (int)(row - b * (unsigned)L);
+    float v = x[i];
+    if (rowtab) v += rowtab[(size_t)l * D + j];
+    if (battab) v += battab[(size_t)b * D + j];
+    out[i] = v;
+  }
+}
+
+hipError_t launch_add_table(const float* x, const float* rowtab, const float* battab, float* out, int B, int L, int D,
+                            hipStream_t s) {
+  const unsigned total = (unsigned)((size_t)B * L * D);
+  unsigned blocks = (total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_add_table, dim3(blocks), dim3(256), 0, s, x, rowtab, battab, out, total, L, D);
+  return hipGetLastError();
+}
+
+// one nn.Embedding(max_norm) lookup-time renormalisation pass (torch embedding_renorm_)
+__global__ void k_renorm_rows_once(float* __restrict__ W, int D, float max_norm) {
+  float* w = W + (size_t)blockIdx.x * D;
+  float ss = 0.f;
+  for (int k = threadIdx.x; k < D; k += WAVE) ss += w[k] * w[k];
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float norm = sqrtf(ss);
+  if (norm > max_norm) {
+    const float scale = max_norm / (norm + 1e-7f);
+    for (int k = threadIdx.x; k < D; k += WAVE) w[k] *= scale;
+  }
+}
+
+hipError_t launch_renorm_rows_once(float* W, int rows, int D, float max_norm, hipStream_t s) {
+  hipLaunchKernelGGL(k_renorm_rows_once, dim3(rows), dim3(WAVE), 0, s, W, D, max_norm);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // unembed: score[row][c] = bu[c] + h[row][:] . Wu[c][:]   (16 lanes per row)
 // ---------------------------------------------------------------------------
 __global__ void k_unembed(const float* __restrict__ h, const float* __restrict__ Wu, const float* __restrict__ bu,

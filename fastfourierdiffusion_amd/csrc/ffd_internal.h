@@ -70,6 +70,9 @@ constexpr __host__ __device__ int w2rem_groups(int D) { return (D % 16) / 4; }
 constexpr __host__ __device__ size_t w2rem_floats(int D, int F) { return (size_t)(F / 16) * (w2rem_groups(D) ? w2rem_groups(D) : 1) * 64 * 4; }
 hipError_t launch_pack_w2rem(const float* W2, float* W2r, int D, int F, hipStream_t s);
 hipError_t launch_renorm_rows(float* W, int rows, int D, float max_norm, hipStream_t s);
+hipError_t launch_renorm_rows_once(float* W, int rows, int D, float max_norm, hipStream_t s);
+hipError_t launch_add_table(const float* x, const float* rowtab, const float* battab, float* out, int B, int L, int D,
+                            hipStream_t s);
 
 // temb[n][d] = dense(gamma(t_n)) for n timesteps (transformer.py:77-91)
 // (ts == nullptr: a single embedding of the immediate t_imm)

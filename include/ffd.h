@@ -166,6 +166,17 @@ int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G,
 int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream);
 int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream);
 
+/* PositionalEncoding.forward (transformer.py:17-29): out = x + weight[arange(L)] for x (B,L,D); like
+ * nn.Embedding(max_norm) the looked-up rows of `weight` (L,D, device) are renormalised IN PLACE first
+ * (rows with ||w|| > max_norm scaled by max_norm/(||w||+1e-7); max_norm <= 0 disables it). */
+int ffd_positional_encoding(const float* x, float* weight, float* out, int B, int L, int D, float max_norm,
+                            void* stream);
+/* GaussianFourierProjection.forward (transformer.py:77-91), use_time_axis=True:
+ * out[b,l,:] = x[b,l,:] + dense([sin(2 pi t_b W), cos(2 pi t_b W)][:D]); timesteps (B) fp32 on device,
+ * temb_work = B*D floats of scratch.  L = 1 gives the use_time_axis=False form. */
+int ffd_time_encoding(const float* x, const float* timesteps, const float* W, const float* dense_w,
+                      const float* dense_b, float* temb_work, float* out, int B, int L, int D, void* stream);
+
 /* FreSca spectral scaling (fdiff.utils.fresca.frequency_scale / apply_fresca_to_score,
  * fresca.py:111-268, 3-D case): out = irfft((low*[k<=Rc] + high*[k>Rc]) (.) rfft(in)) along dim 1.
  * strategy 0 "spatial": Rc = cutoff_ratio * (L/2+1); 1 "energy": Rc = first k whose cumulative

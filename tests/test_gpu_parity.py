@@ -205,6 +205,40 @@ def test_philox_noise_statistics_and_shard_invariance(ffd):
     assert not torch.equal(other, full)
 
 
+# ------------------------------------------------------------ encoders -----
+def test_encoders_reference_tests(ffd, golden):
+    """reference tests/test_transformer.py:18-82 (same sizes, EPS = 1e-5) on the device
+    modules, plus the golden time-embedding known answers."""
+    from fastfourierdiffusion_amd.models.transformer import GaussianFourierProjection, PositionalEncoding
+
+    max_len, batch_size, d_model, EPS = 20, 16, 5, 1e-5
+    torch.manual_seed(42)
+    pos = PositionalEncoding(d_model=d_model, max_len=max_len).cuda()
+    X = torch.randn((batch_size, max_len, d_model), device="cuda")
+    enc = pos(X)
+    assert enc.shape == X.shape
+    assert torch.max(torch.sum((enc - X) ** 2, dim=-1)) <= d_model + EPS  # max_norm constraint
+    assert torch.allclose((enc - X)[3], pos.embedding.weight[:max_len], atol=EPS)
+    te = GaussianFourierProjection(d_model=d_model).cuda()
+    ts = torch.randint(low=0, high=max_len, size=(batch_size,), device="cuda").float()
+    out = te(X, ts)
+    proj = ts[:, None].cpu() * te.W[None, :].cpu() * 2 * np.pi
+    emb = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)[:, :d_model]
+    gt = torch.nn.functional.linear(emb, te.dense.weight.cpu(), te.dense.bias.cpu())
+    assert torch.allclose((out - X).cpu(), gt[:, None, :].expand(-1, max_len, -1), atol=EPS * 10)
+    # golden known answer (default ECG model weights)
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    for tv in c["t_values"]:
+        t = torch.full((c["B"],), tv, device="cuda")
+        got = m.time_encoder(torch.zeros(c["B"], 1, c["d"], device="cuda"), t)[:, 0, :]
+        np.testing.assert_allclose(got.cpu().numpy(), golden["g5_models"][f"ecg_temb_t{tv}"], rtol=0, atol=1e-5)
+    pe = m.pos_encoder(torch.zeros(1, c["L"], c["d"], device="cuda"))
+    for _ in range(3):
+        pe = m.pos_encoder(torch.zeros(1, c["L"], c["d"], device="cuda"))
+    np.testing.assert_allclose(pe[0].cpu().numpy(), golden["g5_models"]["ecg_pos_fixed"], rtol=0, atol=1e-6)
+
+
 # -------------------------------------------------------------- models -----
 @pytest.fixture(params=["auto", "fused", "valu_attn", "mfma4x4_attn"])
 def variant(request, ffd):
