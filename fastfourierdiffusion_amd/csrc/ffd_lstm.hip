@@ -12,6 +12,16 @@ namespace ffd {
 
 constexpr int LSTM_BT = 2;
 
+// sigmoid / tanh from one v_exp_f32 + one v_rcp_f32 each (absolute error ~1e-7, far inside the
+// parity tolerance; the library expf / tanhf cost ~10x the instructions on the critical path)
+__device__ __forceinline__ float sigmoid_fast(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+  // 1 - 2/(exp(2x)+1); exp2 overflow -> rcp(inf) = 0 -> 1, underflow -> 1 - 2 = -1
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
 template <int D>
 __global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const float* __restrict__ gx,
                                                     const float* __restrict__ whh, int B, int L) {
@@ -53,29 +63,34 @@ __global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const
       }
     }
     if (gate_thread) {
+      // four partial sums per sample: the recurrence is latency-bound, so the 72-long dot
+      // product must not be one dependent FMA chain
+      float p1[LSTM_BT], p2[LSTM_BT], p3[LSTM_BT];
+#pragma unroll
+      for (int bt = 0; bt < LSTM_BT; ++bt) p1[bt] = p2[bt] = p3[bt] = 0.f;
 #pragma unroll
       for (int k = 0; k < D; k += 4) {
 #pragma unroll
         for (int bt = 0; bt < LSTM_BT; ++bt) {
           const float4 hv = *reinterpret_cast<const float4*>(&hbuf[bt][k]);  // broadcast
           g[bt] = fmaf(w[k], hv.x, g[bt]);
-          g[bt] = fmaf(w[k + 1], hv.y, g[bt]);
-          g[bt] = fmaf(w[k + 2], hv.z, g[bt]);
-          g[bt] = fmaf(w[k + 3], hv.w, g[bt]);
+          p1[bt] = fmaf(w[k + 1], hv.y, p1[bt]);
+          p2[bt] = fmaf(w[k + 2], hv.z, p2[bt]);
+          p3[bt] = fmaf(w[k + 3], hv.w, p3[bt]);
         }
       }
 #pragma unroll
-      for (int bt = 0; bt < LSTM_BT; ++bt) gates[bt][tid] = g[bt];
+      for (int bt = 0; bt < LSTM_BT; ++bt) gates[bt][tid] = (g[bt] + p1[bt]) + (p2[bt] + p3[bt]);
     }
     __syncthreads();
     if (cell_thread) {
       const float gi = gates[cbt][ce], gf = gates[cbt][D + ce], gg = gates[cbt][2 * D + ce],
                   go = gates[cbt][3 * D + ce];
-      const float si = 1.0f / (1.0f + expf(-gi));
-      const float sf = 1.0f / (1.0f + expf(-gf));
-      const float so = 1.0f / (1.0f + expf(-go));
-      c = sf * c + si * tanhf(gg);
-      const float h = so * tanhf(c);
+      const float si = sigmoid_fast(gi);
+      const float sf = sigmoid_fast(gf);
+      const float so = sigmoid_fast(go);
+      c = sf * c + si * tanh_fast(gg);
+      const float h = so * tanh_fast(c);
       hbuf[cbt][ce] = h;
       if (cell_valid) {
         float* xr = x + ((size_t)(b0 + cbt) * L + s) * D + ce;
