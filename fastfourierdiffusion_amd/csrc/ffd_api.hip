@@ -112,8 +112,18 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
 
 static int g_bench_kernel = 0;
 
-static bool d_supported(int d) { return d == 24 || d == 60 || d == 72; }
-static bool hd_supported(int hd) { return hd == 4 || hd == 5 || hd == 6 || hd == 8; }
+static bool d_supported(int d) {
+#define X(v) if (d == v) return true;
+  FFD_D_LIST(X)
+#undef X
+  return false;
+}
+static bool hd_supported(int hd) {
+#define X(v) if (hd == v) return true;
+  FFD_HD_LIST(X)
+#undef X
+  return false;
+}
 
 extern "C" {
 
@@ -212,12 +222,12 @@ int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
   if (m.n_channels < 1 || m.max_len < 1 || m.num_layers < 1)
     return ctx->fail(FFD_ERR_INVALID, "bad shape: C=%d L=%d NL=%d", m.n_channels, m.max_len, m.num_layers);
   if (!d_supported(m.d_model))
-    return ctx->fail(FFD_ERR_UNSUPPORTED, "d_model=%d: this build has kernels for d_model in {24, 60, 72}", m.d_model);
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "d_model=%d: this build has kernels for d_model in {8, 16, 24, 32, 48, 60, 64, 72}", m.d_model);
   if (m.kind == FFD_MODEL_TRANSFORMER) {
     if (m.n_head < 1 || m.d_model % m.n_head != 0)
       return ctx->fail(FFD_ERR_INVALID, "d_model=%d not divisible by n_head=%d", m.d_model, m.n_head);
     if (!hd_supported(m.d_model / m.n_head))
-      return ctx->fail(FFD_ERR_UNSUPPORTED, "head_dim=%d: supported head dims are 4, 5, 6, 8", m.d_model / m.n_head);
+      return ctx->fail(FFD_ERR_UNSUPPORTED, "head_dim=%d: supported head dims are 2, 3, 4, 5, 6, 8", m.d_model / m.n_head);
     if (m.dim_feedforward < 64 || m.dim_feedforward % 64 != 0)
       return ctx->fail(FFD_ERR_UNSUPPORTED, "dim_feedforward=%d must be a positive multiple of 64", m.dim_feedforward);
     if (m.max_len > 512) return ctx->fail(FFD_ERR_UNSUPPORTED, "max_len=%d > 512 (attention kernel limit)", m.max_len);

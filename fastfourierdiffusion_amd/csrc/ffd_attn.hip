@@ -513,27 +513,27 @@ hipError_t launch_attention(const float* qkv, const float* k, const float* v, co
   if (B <= 0) return hipSuccess;
   if (g_attn_impl == 2) {
     switch (hd) {
-      case 4: return launch_attn_v3<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 5: return launch_attn_v3<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 6: return launch_attn_v3<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 8: return launch_attn_v3<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+#define X(h) \
+      case h: return launch_attn_v3<h>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      FFD_HD_LIST(X)
+#undef X
       default: return hipErrorInvalidValue;
     }
   }
   if (g_attn_impl == 0) {
     switch (hd) {
-      case 4: return launch_attn_mfma_hd<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 5: return launch_attn_mfma_hd<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 6: return launch_attn_mfma_hd<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-      case 8: return launch_attn_mfma_hd<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+#define X(h) \
+      case h: return launch_attn_mfma_hd<h>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      FFD_HD_LIST(X)
+#undef X
       default: return hipErrorInvalidValue;
     }
   }
   switch (hd) {
-    case 4: return launch_attn_hd<4>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-    case 5: return launch_attn_hd<5>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-    case 6: return launch_attn_hd<6>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
-    case 8: return launch_attn_hd<8>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+#define X(h) \
+    case h: return launch_attn_hd<h>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+    FFD_HD_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
 }

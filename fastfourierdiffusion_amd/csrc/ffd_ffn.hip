@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
   constexpr int CTP = cdiv(D, 16);                       // tiles in the packed w2 image
-  constexpr int NG = REM ? w2rem_groups(D) : 0;           // 4-row remainder groups on the 4x4x1 path
+  constexpr int NG = (REM && D >= 16) ? w2rem_groups(D) : 0;  // 4-row remainder groups on the 4x4x1 path
   constexpr int CT = (NG > 0) ? D / 16 : cdiv(D, 16);     // 16-row tiles on the 16x16x4 path
   constexpr int NGA = NG > 0 ? NG : 1;
   constexpr int R = 16 * MB;
@@ -281,7 +281,7 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   dim3 block(256);
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
-    if (g_ffn_rem && MBV == 4 && w2rem_groups(D) > 0)                                                                       \
+    if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,   \
                          w.w2r, w.b2, w.n2w, w.n2b, Y, M, F);                                                     \
     else                                                                                                          \
@@ -302,9 +302,10 @@ hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M,
   if (M <= 0) return hipSuccess;
   if (F % 64 != 0) return hipErrorInvalidValue;
   switch (D) {
-    case 24: return launch_ffn_d<24>(X, w, Y, M, F, s);
-    case 60: return launch_ffn_d<60>(X, w, Y, M, F, s);
-    case 72: return launch_ffn_d<72>(X, w, Y, M, F, s);
+#define X(d) \
+    case d: return launch_ffn_d<d>(X, w, Y, M, F, s);
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
 }

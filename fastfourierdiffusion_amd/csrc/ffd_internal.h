@@ -7,6 +7,10 @@ namespace ffd {
 
 constexpr int WAVE = 64;
 
+// d_model / head_dim values with compiled kernels (every d % 4 == 0, d <= 72; hd <= 8)
+#define FFD_D_LIST(X) X(8) X(16) X(24) X(32) X(48) X(60) X(64) X(72)
+#define FFD_HD_LIST(X) X(2) X(3) X(4) X(5) X(6) X(8)
+
 // ---- MFMA f32 16x16x4 fragment conventions (cdna_hip_programming.md §3) ----
 //   A operand: lane l holds A[i = l & 15][k = l >> 4]
 //   B operand: lane l holds B[k = l >> 4][j = l & 15]

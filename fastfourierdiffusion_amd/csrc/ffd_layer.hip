@@ -335,9 +335,10 @@ hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights
   if (F % 64 != 0) return hipErrorInvalidValue;
   dim3 grid(cdiv(M, 64)), block(256);
   switch (D) {
-    case 24: hipLaunchKernelGGL(k_layer<24>, grid, block, 0, s, attn, xres, w, Y, nx, M, F); break;
-    case 60: hipLaunchKernelGGL(k_layer<60>, grid, block, 0, s, attn, xres, w, Y, nx, M, F); break;
-    case 72: hipLaunchKernelGGL(k_layer<72>, grid, block, 0, s, attn, xres, w, Y, nx, M, F); break;
+#define X(d) \
+    case d: hipLaunchKernelGGL(k_layer<d>, grid, block, 0, s, attn, xres, w, Y, nx, M, F); break;
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -269,9 +269,10 @@ hipError_t launch_linear(const float* X, const float* Wp, const float* bias, flo
   if (M <= 0) return hipSuccess;
   dim3 grid(cdiv(M, 64)), block(256);
   switch (D) {
-    case 24: hipLaunchKernelGGL(k_linear<24>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
-    case 60: hipLaunchKernelGGL(k_linear<60>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
-    case 72: hipLaunchKernelGGL(k_linear<72>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+#define X(d) \
+    case d: hipLaunchKernelGGL(k_linear<d>, grid, block, 0, s, X, Wp, bias, Y, M, N, ldy); break;
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -286,9 +287,10 @@ hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, 
   const unsigned hd_inv = (65536u + hd - 1) / hd;  // exact floor(c / hd) for c < 2^16 / hd
   dim3 grid(cdiv(M, 32)), block(256);
   switch (D) {
-    case 24: hipLaunchKernelGGL(k_linear_hm<24>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
-    case 60: hipLaunchKernelGGL(k_linear_hm<60>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
-    case 72: hipLaunchKernelGGL(k_linear_hm<72>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
+#define X(d) \
+    case d: hipLaunchKernelGGL(k_linear_hm<d>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -299,9 +301,10 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
   if (M <= 0) return hipSuccess;
   dim3 grid(cdiv(M, 64)), block(256);
   switch (D) {
-    case 24: hipLaunchKernelGGL(k_linear_res_ln<24>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
-    case 60: hipLaunchKernelGGL(k_linear_res_ln<60>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
-    case 72: hipLaunchKernelGGL(k_linear_res_ln<72>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
+#define X(d) \
+    case d: hipLaunchKernelGGL(k_linear_res_ln<d>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

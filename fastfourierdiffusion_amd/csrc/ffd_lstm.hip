@@ -105,9 +105,10 @@ hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B,
   if (B <= 0) return hipSuccess;
   dim3 grid(cdiv(B, LSTM_BT));
   switch (D) {
-    case 24: hipLaunchKernelGGL(k_lstm_layer<24>, grid, dim3(128), 0, s, x, gx, whh, B, L); break;
-    case 60: hipLaunchKernelGGL(k_lstm_layer<60>, grid, dim3(256), 0, s, x, gx, whh, B, L); break;
-    case 72: hipLaunchKernelGGL(k_lstm_layer<72>, grid, dim3(320), 0, s, x, gx, whh, B, L); break;
+#define X(d) \
+    case d: hipLaunchKernelGGL(k_lstm_layer<d>, grid, dim3(((4 * d + 63) / 64) * 64), 0, s, x, gx, whh, B, L); break;
+    FFD_D_LIST(X)
+#undef X
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

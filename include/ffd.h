@@ -55,7 +55,7 @@ typedef struct {
   int32_t kind;            /* FFD_MODEL_* */
   int32_t n_channels;      /* C */
   int32_t max_len;         /* L */
-  int32_t d_model;         /* d   (transformer: 24, 60 or 72 in this build; lstm: same) */
+  int32_t d_model;         /* d   (8, 16, 24, 32, 48, 60, 64 or 72 in this build; d / n_head in {2,3,4,5,6,8}) */
   int32_t n_head;          /* H   (ignored for lstm) */
   int32_t num_layers;      /* NL */
   int32_t dim_feedforward; /* F   (PyTorch default 2048, score_models.py:61-63); multiple of 64 */

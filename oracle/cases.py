@@ -26,6 +26,8 @@ STEP_CASES = [
 ]
 
 _SMALL = dict(kind="transformer", d=24, H=4, NL=2, L=20, C=3)          # hd = 6
+_REFUNIT = dict(kind="transformer", d=8, H=4, NL=2, L=20, C=3)          # tests/test_score_models.py:13-19 (hd = 2)
+_REFUNIT_LSTM = dict(kind="lstm", d=8, H=1, NL=2, L=20, C=3)
 _REFTEST = dict(kind="transformer", d=60, H=12, NL=3, L=50, C=3)       # tests/test_sampling.py:7-11 (hd = 5)
 _ECG = dict(kind="transformer", d=72, H=12, NL=10, L=187, C=1)         # cmd/conf/score_model/default.yaml
 _SYN = dict(kind="transformer", d=72, H=12, NL=10, L=512, C=8)         # BASELINE configs[4] shape
@@ -42,6 +44,10 @@ MODEL_CASES = [
          t_values=[1.0, 0.25], cache_seq=[list(range(187)), [], list(range(10)), []], dump_table=False),
     dict(name="syn", **_SYN, sde="vp", sde_kwargs=VP, fourier=True, B=1, wseed=44, xseed=34,
          t_values=[0.9], cache_seq=[list(range(512)), [], list(range(10))], dump_table=False),
+    dict(name="refunit", **_REFUNIT, sde="vp", sde_kwargs=VP, fourier=True, B=5, wseed=47, xseed=37,
+         t_values=[0.5], cache_seq=[list(range(20)), [], list(range(10))], dump_table=True),
+    dict(name="refunit_lstm", **_REFUNIT_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=5, wseed=48, xseed=38,
+         t_values=[0.5]),
     dict(name="nasa_lstm", **_NASA_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=2, wseed=45, xseed=35,
          t_values=[1.0, 0.3]),
     dict(name="small_lstm", **_SMALL_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=3, wseed=46, xseed=36,
@@ -66,6 +72,8 @@ TRAJ_CASES = [
     dict(name="traj_small_fresca_cache_spatial", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=2,
          num_samples=2, N=8, use_cache=True, cache_kwargs={}, wseed=42, zseed=63,
          fresca=dict(low_scale=0.9, high_scale=1.2, cutoff_ratio=0.4, cutoff_strategy="spatial")),
+    dict(name="traj_refunit_ve", **_REFUNIT, sde="ve", sde_kwargs=VE, fourier=True, B=5, num_samples=5, N=10,
+         use_cache=False, wseed=47, zseed=64),
     dict(name="traj_small_time", **_SMALL, sde="vp", sde_kwargs=VP, fourier=False, B=2, num_samples=2, N=8,
          use_cache=False, wseed=42, zseed=56),
     dict(name="traj_reftest_vp", **_REFTEST, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2, N=10,

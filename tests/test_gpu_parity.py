@@ -375,6 +375,26 @@ def test_traj_golden(ffd, golden, c, variant):
     assert err < TOL_TRAJ, err
 
 
+def test_reference_unit_test_sizes(ffd):
+    """reference tests/test_score_models.py:13-89 and tests/test_schedulers.py:14-18,123-135: the
+    d_model=8 / n_head=4 / num_layers=2 models produce (batch, max_len, n_channels) scores and
+    (num_samples, max_len, n_channels) samples."""
+    from fastfourierdiffusion_amd.models.score_models import LSTMScoreModule, ScoreModule
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    from fastfourierdiffusion_amd.schedulers.sde import VEScheduler, VPScheduler
+
+    for sch in (VPScheduler(), VEScheduler()):
+        for cls, kw in ((ScoreModule, dict(n_head=4)), (LSTMScoreModule, {})):
+            model = cls(n_channels=3, max_len=20, noise_scheduler=sch, d_model=8, num_layers=2,
+                        num_training_steps=10, **kw).cuda()
+            sch.set_noise_scaling(20)
+            X = torch.randn(5, 20, 3, device="cuda")
+            score = model(batch_of(X, 0.5))
+            assert score.shape == X.shape and torch.isfinite(score).all()
+            samples = DiffusionSampler(score_model=model, sample_batch_size=12).sample(48, 10)
+            assert samples.shape == (48, 20, 3) and torch.isfinite(samples).all()
+
+
 def test_sampler_api_shapes_reference_test(ffd):
     """reference tests/test_sampling.py:21-40: default ScoreModule (d=60, H=12, NL=3),
     sample(48, 10) with batch 12 -> (48, 50, 3), VP and VE, torch-seeded RNG."""
