@@ -157,29 +157,28 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_attention_mfma(const
   constexpr int KST = (HD + 1) / 2;  // MFMA k-steps
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wpb = blockDim.x >> 6;
-  const int pair = blockIdx.x * wpb + wave;
+  const int nwaves = blockDim.x >> 6;
+  const int pair = blockIdx.x;  // one workgroup = one (sample, head); its waves split the q-tile groups
   const int d = H * HD;
-  const bool active = pair < B * H;
-  const int b = active ? pair / H : 0, h = active ? pair % H : 0;
+  const int b = pair / H, h = pair - b * H;
   const int KT = (L + 31) >> 5;
   const int Lp = KT * 32;
-  // per-wave LDS: V rows [Lp][8] (zero padded) then K^T [2*KST][Lp]
-  float* vs = lds + (size_t)wave * Lp * (8 + 2 * KST);
+  // LDS image of the head, staged once by the whole workgroup: V rows [Lp][8] (zero padded), K^T [2*KST][Lp]
+  float* vs = lds;
   float* kts = vs + (size_t)Lp * 8;
   const int half = lane >> 5, l31 = lane & 31;
 
-  // zero the padded images, then fill from the contiguous head-major slices (coalesced)
-  for (int idx = lane; idx < Lp * (8 + 2 * KST); idx += 64) vs[idx] = 0.f;
+  for (int idx = threadIdx.x; idx < Lp * (8 + 2 * KST); idx += blockDim.x) vs[idx] = 0.f;
+  __syncthreads();
   const size_t slice = (size_t)pair * L * HD;
-  if (active) {
+  {
     const float* kown = kg + slice;
     const float* vown = vg + slice;
     const float* ktab = kt ? kt + (size_t)h * L * HD : kown;
     const float* vtab = vt ? vt + (size_t)h * L * HD : vown;
     const int own_elems = n_own * HD;
 #pragma unroll 4
-    for (int idx = lane; idx < L * HD; idx += 64) {
+    for (int idx = threadIdx.x; idx < L * HD; idx += blockDim.x) {
       const int j = idx / HD, e = idx - j * HD;
       const bool own = idx < own_elems;
       const float kx = (own ? kown : ktab)[idx];
@@ -189,11 +188,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_attention_mfma(const
     }
   }
   __syncthreads();
-  if (!active) return;
 
   const float c = 1.4426950408889634f / sqrtf((float)HD);
   const int QT = KT;
-  for (int qt0 = 0; qt0 < QT; qt0 += QG) {
+  for (int qt0 = wave * QG; qt0 < QT; qt0 += nwaves * QG) {
     float qf[QG][KST], m[QG], lsum[QG], acc[QG][HD];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -296,13 +294,12 @@ template <int HD, int QG>
 static hipError_t launch_attn_mfma_t(const float* q, const float* k, const float* v, const float* kt,
                                      const float* vt, float* out, int B, int L, int H, int n_own, hipStream_t s) {
   constexpr int KST = (HD + 1) / 2;
-  const int Lp = ((L + 31) / 32) * 32;
-  const size_t per_wave = (size_t)Lp * (8 + 2 * KST) * sizeof(float);
-  int wpb = 4;
-  while (wpb > 1 && per_wave * wpb > 48 * 1024) wpb >>= 1;
-  const int pairs = B * H;
-  hipLaunchKernelGGL((k_attention_mfma<HD, QG>), dim3(cdiv(pairs, wpb)), dim3(64 * wpb), per_wave * wpb, s, q, k, v,
-                     kt, vt, out, B, L, H, n_own);
+  const int KT = (L + 31) / 32;
+  const size_t lds = (size_t)KT * 32 * (8 + 2 * KST) * sizeof(float);
+  int nwaves = cdiv(KT, QG);  // one wave per q-tile group, at most 4 (further groups are looped)
+  if (nwaves > 4) nwaves = 4;
+  hipLaunchKernelGGL((k_attention_mfma<HD, QG>), dim3(B * H), dim3(64 * nwaves), lds, s, q, k, v, kt, vt, out, B, L, H,
+                     n_own);
   return hipGetLastError();
 }
 
