@@ -10,7 +10,7 @@
 
 namespace ffd {
 
-constexpr int LSTM_BT = 2;
+// (samples per workgroup are chosen per d_model in launch_lstm_layer)
 
 // sigmoid / tanh from one v_exp_f32 + one v_rcp_f32 each (absolute error ~1e-7, far inside the
 // parity tolerance; the library expf / tanhf cost ~10x the instructions on the critical path)
@@ -22,57 +22,102 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-template <int D>
+// Thread layout: tid = 4*e + gate -- the four gates (i, f, g, o) of hidden unit e sit in one lane quad,
+// so after the dot products the activated gate values are exchanged with four DPP quad-broadcasts
+// (no LDS round trip), every lane of the quad updates c/h redundantly, and one barrier per cell step
+// (h is double-buffered in LDS) is all the synchronisation the recurrence needs.
+template <int K>
+__device__ __forceinline__ float quad_bcast(float v) {
+  // quad_perm:[K,K,K,K] : every lane of a quad reads lane K of that quad
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v),
+                                                               K | (K << 2) | (K << 4) | (K << 6), 0xF, 0xF, true));
+}
+
+// Global memory is touched once per chunk of CH cell steps, not once per step: the gate
+// pre-activations gx and the residual rows of the next chunk are loaded into registers while the
+// current chunk runs (their latency is hidden behind CH recurrence steps), parked in LDS at the
+// chunk boundary, and the inner loop works on LDS only (a per-step global load would put a full
+// s_waitcnt vmcnt(0) memory round trip on the critical path of every cell step).
+template <int D, int BT>
 __global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const float* __restrict__ gx,
                                                     const float* __restrict__ whh, int B, int L) {
   constexpr int G4 = 4 * D;
-  __shared__ __align__(16) float hbuf[LSTM_BT][D];
-  __shared__ float gates[LSTM_BT][G4];
+  constexpr int CH = 16;
+  constexpr int GQ = CH * G4 / 4;  // float4 per sample per chunk (gate pre-activations)
+  constexpr int XQ = CH * D / 4;   // float4 per sample per chunk (residual rows)
+  constexpr int NT = ((G4 + 63) / 64) * 64;
+  constexpr int GPT = (GQ + NT - 1) / NT, XPT = (XQ + NT - 1) / NT;
+  __shared__ __align__(16) float hbuf[2][BT][D];
+  __shared__ __align__(16) float gxs[BT][CH * G4];
+  __shared__ __align__(16) float xsb[BT][CH * D];
   const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * LSTM_BT;
-  const bool gate_thread = tid < G4;
+  const int b0 = blockIdx.x * BT;
+  const bool live = tid < G4;
+  const int e = live ? tid >> 2 : 0, gate = tid & 3;
+  const int rowi = gate * D + e;  // row of W_hh / column of the gate pre-activations
+  const bool writer = live && gate == 0;
 
   float w[D];
-  if (gate_thread) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) w[k] = whh[(size_t)tid * D + k];
-  }
-  // cell threads: (bt, e)
-  const bool cell_thread = tid < LSTM_BT * D;
-  const int cbt = tid / D, ce = tid - cbt * D;
-  const bool cell_valid = cell_thread && (b0 + cbt) < B;
-  float c = 0.f;
-  for (int i = tid; i < LSTM_BT * D; i += blockDim.x) (&hbuf[0][0])[i] = 0.f;
-  __syncthreads();
+  for (int k = 0; k < D; ++k) w[k] = whh[(size_t)rowi * D + k];
+  float c[BT];
+#pragma unroll
+  for (int bt = 0; bt < BT; ++bt) c[bt] = 0.f;
+  for (int i = tid; i < 2 * BT * D; i += blockDim.x) (&hbuf[0][0][0])[i] = 0.f;
 
-  float gnext[LSTM_BT];
+  // activation constants: gate 2 (g) is tanh, the others sigmoid; both are rcp(1 + exp2(s*x)) based
+  const float sarg = (gate == 2) ? 2.8853900817779268f : -1.4426950408889634f;
+
+  float4 gq[BT][GPT], xq[BT][XPT];
+  auto fetch = [&](int s0) {  // chunk starting at step s0 -> registers (zero beyond L)
+    const int nst = min(CH, L - s0);
 #pragma unroll
-  for (int bt = 0; bt < LSTM_BT; ++bt) {
-    const int b = min(b0 + bt, B - 1);
-    gnext[bt] = gate_thread ? gx[((size_t)b * L) * G4 + tid] : 0.f;
-  }
-  for (int s = 0; s < L; ++s) {
-    float g[LSTM_BT];
+    for (int bt = 0; bt < BT; ++bt) {
+      const int b = min(b0 + bt, B - 1);
+      const float4* g4 = reinterpret_cast<const float4*>(gx + ((size_t)b * L + s0) * G4);
+      const float4* x4 = reinterpret_cast<const float4*>(x + ((size_t)b * L + s0) * D);
 #pragma unroll
-    for (int bt = 0; bt < LSTM_BT; ++bt) g[bt] = gnext[bt];
-    if (s + 1 < L) {
+      for (int i = 0; i < GPT; ++i) {
+        const int q = tid + i * NT;
+        gq[bt][i] = (q < nst * G4 / 4) ? g4[q] : float4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-      for (int bt = 0; bt < LSTM_BT; ++bt) {
-        const int b = min(b0 + bt, B - 1);
-        gnext[bt] = gate_thread ? gx[((size_t)b * L + s + 1) * G4 + tid] : 0.f;
+      for (int i = 0; i < XPT; ++i) {
+        const int q = tid + i * NT;
+        xq[bt][i] = (q < nst * D / 4) ? x4[q] : float4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (gate_thread) {
-      // four partial sums per sample: the recurrence is latency-bound, so the 72-long dot
-      // product must not be one dependent FMA chain
-      float p1[LSTM_BT], p2[LSTM_BT], p3[LSTM_BT];
+  };
+  fetch(0);
+  int step = 0;
+  for (int s0 = 0; s0 < L; s0 += CH) {
+    const int nst = min(CH, L - s0);
+    // park the prefetched chunk in LDS
 #pragma unroll
-      for (int bt = 0; bt < LSTM_BT; ++bt) p1[bt] = p2[bt] = p3[bt] = 0.f;
+    for (int bt = 0; bt < BT; ++bt) {
+#pragma unroll
+      for (int i = 0; i < GPT; ++i) {
+        const int q = tid + i * NT;
+        if (q < GQ) reinterpret_cast<float4*>(gxs[bt])[q] = gq[bt][i];
+      }
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int q = tid + i * NT;
+        if (q < XQ) reinterpret_cast<float4*>(xsb[bt])[q] = xq[bt][i];
+      }
+    }
+    __syncthreads();
+    if (s0 + CH < L) fetch(s0 + CH);  // next chunk: in flight during the nst steps below
+    for (int sl = 0; sl < nst; ++sl, ++step) {
+      const int cur = step & 1;
+      float g[BT], p1[BT], p2[BT], p3[BT];
+#pragma unroll
+      for (int bt = 0; bt < BT; ++bt) g[bt] = gxs[bt][sl * G4 + rowi], p1[bt] = p2[bt] = p3[bt] = 0.f;
 #pragma unroll
       for (int k = 0; k < D; k += 4) {
 #pragma unroll
-        for (int bt = 0; bt < LSTM_BT; ++bt) {
-          const float4 hv = *reinterpret_cast<const float4*>(&hbuf[bt][k]);  // broadcast
+        for (int bt = 0; bt < BT; ++bt) {
+          const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][bt][k]);  // broadcast
           g[bt] = fmaf(w[k], hv.x, g[bt]);
           p1[bt] = fmaf(w[k + 1], hv.y, p1[bt]);
           p2[bt] = fmaf(w[k + 2], hv.z, p2[bt]);
@@ -80,21 +125,26 @@ __global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const
         }
       }
 #pragma unroll
-      for (int bt = 0; bt < LSTM_BT; ++bt) gates[bt][tid] = (g[bt] + p1[bt]) + (p2[bt] + p3[bt]);
+      for (int bt = 0; bt < BT; ++bt) {
+        const float pre = (g[bt] + p1[bt]) + (p2[bt] + p3[bt]);
+        const float t = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sarg * pre));
+        const float a = (gate == 2) ? 1.0f - 2.0f * t : t;  // own gate, activated
+        const float ai = quad_bcast<0>(a), af = quad_bcast<1>(a), ag = quad_bcast<2>(a), ao = quad_bcast<3>(a);
+        c[bt] = af * c[bt] + ai * ag;
+        const float h = ao * tanh_fast(c[bt]);
+        if (writer) {
+          hbuf[cur ^ 1][bt][e] = h;
+          xsb[bt][sl * D + e] += h;  // residual: x <- x + LSTM(x)
+        }
+      }
+      __syncthreads();  // LDS only inside this loop
     }
-    __syncthreads();
-    if (cell_thread) {
-      const float gi = gates[cbt][ce], gf = gates[cbt][D + ce], gg = gates[cbt][2 * D + ce],
-                  go = gates[cbt][3 * D + ce];
-      const float si = sigmoid_fast(gi);
-      const float sf = sigmoid_fast(gf);
-      const float so = sigmoid_fast(go);
-      c = sf * c + si * tanh_fast(gg);
-      const float h = so * tanh_fast(c);
-      hbuf[cbt][ce] = h;
-      if (cell_valid) {
-        float* xr = x + ((size_t)(b0 + cbt) * L + s) * D + ce;
-        *xr = *xr + h;
+    // write the chunk's output rows back (coalesced)
+#pragma unroll
+    for (int bt = 0; bt < BT; ++bt) {
+      if (b0 + bt < B) {
+        float4* o4 = reinterpret_cast<float4*>(x + ((size_t)(b0 + bt) * L + s0) * D);
+        for (int q = tid; q < nst * D / 4; q += blockDim.x) o4[q] = reinterpret_cast<const float4*>(xsb[bt])[q];
       }
     }
     __syncthreads();
@@ -103,10 +153,11 @@ __global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  dim3 grid(cdiv(B, LSTM_BT));
+  // two samples per workgroup while the W_hh row + chunk registers fit, one for d_model >= 64
   switch (D) {
 #define X(d) \
-    case d: hipLaunchKernelGGL(k_lstm_layer<d>, grid, dim3(((4 * d + 63) / 64) * 64), 0, s, x, gx, whh, B, L); break;
+    case d: hipLaunchKernelGGL((k_lstm_layer<d, (d >= 60 ? 1 : 2)>), dim3(cdiv(B, (d >= 60 ? 1 : 2))), dim3(((4 * d + 63) / 64) * 64), 0, s, \
+                               x, gx, whh, B, L); break;
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;
