@@ -108,6 +108,32 @@ class ScoreModule(nn.Module):
         self.dim_feedforward = layer.linear1.out_features
 
     # ------------------------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, hparams_file=None, strict: bool = True,
+                             weights_only=None, **kwargs):
+        """LightningModule.load_from_checkpoint as the reference's runners call it
+        (cmd/sample.py:68-75, cmd/benchmark_cache.py:141-144): rebuild the module from the
+        checkpoint's ``hyper_parameters`` (saved by ``save_hyperparameters``, score_models.py:71)
+        and load its ``state_dict``.  The file is always read with ``torch.load(weights_only=True)``
+        (the scheduler classes are allow-listed), whatever ``weights_only`` the caller passes;
+        ``cached_backbone.*`` entries (copies made by enable_caching) are ignored."""
+        import inspect
+
+        from ..schedulers import sde as _sde
+
+        safe = [_sde.VPScheduler, _sde.VEScheduler]
+        with torch.serialization.safe_globals(safe):
+            ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(kwargs)
+        accepted = set(inspect.signature(cls.__init__).parameters) - {"self"}
+        model = cls(**{k: v for k, v in hp.items() if k in accepted})
+        sd = {k: v for k, v in ckpt["state_dict"].items() if not k.startswith("cached_backbone.")}
+        model.load_state_dict(sd, strict=strict)
+        if map_location is not None:
+            model = model.to(map_location)
+        return model
+
     @property
     def device(self) -> torch.device:
         try:

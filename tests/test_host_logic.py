@@ -174,6 +174,38 @@ def test_same_seed_same_init_as_torch_reference_modules():
     assert torch.equal(m.embedder.weight, embedder.weight)
 
 
+def test_load_from_checkpoint_roundtrip(tmp_path):
+    """cmd/sample.py:68-75 path: a Lightning-style checkpoint (hyper_parameters + state_dict, with the
+    scheduler object pickled under the reference's module path) loads through the mirror.  No real
+    checkpoint exists in this environment, so the file is synthesised here (parity unpinned)."""
+    import fastfourierdiffusion_amd as pkg
+
+    pkg.install_as_fdiff(force=True)
+    from fdiff.models.score_models import LSTMScoreModule, ScoreModule
+    from fdiff.schedulers.sde import VPScheduler
+
+    sch = VPScheduler(beta_min=0.1, beta_max=20, fourier_noise_scaling=True)
+    src = ScoreModule(n_channels=2, max_len=12, noise_scheduler=sch, d_model=24, num_layers=2, n_head=4)
+    sd = dict(src.state_dict())
+    sd["cached_backbone.0.linear1.weight"] = torch.zeros(3)  # left behind by enable_caching during training
+    ckpt = {"state_dict": sd, "pytorch-lightning_version": "2.1.0", "epoch": 3,
+            "hyper_parameters": dict(n_channels=2, max_len=12, noise_scheduler=sch, fourier_noise_scaling=True,
+                                     d_model=24, num_layers=2, n_head=4, num_training_steps=1000, lr_max=1e-3,
+                                     likelihood_weighting=False)}
+    path = tmp_path / "epoch=3.ckpt"
+    torch.save(ckpt, path)
+    m = ScoreModule.load_from_checkpoint(checkpoint_path=str(path), weights_only=False)
+    assert isinstance(m.noise_scheduler, VPScheduler) and m.noise_scheduler.beta_1 == 20 and m.max_len == 12
+    for k, v in src.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v), k
+    l_src = LSTMScoreModule(n_channels=2, max_len=12, noise_scheduler=sch, d_model=8, num_layers=2)
+    torch.save({"state_dict": l_src.state_dict(),
+                "hyper_parameters": dict(n_channels=2, max_len=12, noise_scheduler=sch, d_model=8, num_layers=2)},
+               tmp_path / "l.ckpt")
+    lm = LSTMScoreModule.load_from_checkpoint(tmp_path / "l.ckpt")
+    assert torch.equal(lm.state_dict()["backbone.1.weight_hh_l0"], l_src.state_dict()["backbone.1.weight_hh_l0"])
+
+
 def test_cpu_tensors_are_refused():
     from fastfourierdiffusion_amd._native import FFDError
     from fastfourierdiffusion_amd.models.score_models import ScoreModule
