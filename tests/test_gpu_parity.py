@@ -28,10 +28,16 @@ TOL_TRAJ = 1e-5
 @pytest.fixture(scope="module")
 def ffd():
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import os
+
     import fastfourierdiffusion_amd as pkg
     from fastfourierdiffusion_amd import _native
 
-    _native.lib()  # fail loudly if libffd.so is missing
+    if not os.path.exists(_native.LIB_PATH):  # the in-tree build normally travels with the snapshot
+        from fastfourierdiffusion_amd.build import build
+
+        build()
+    _native.lib()  # fail loudly if libffd.so cannot be loaded
     return pkg
 
 
