@@ -148,10 +148,6 @@ int ffd_tune(const char* key, int value) {
     g_fuse_layer = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "dbg")) {
-    g_dbg = value;
-    return FFD_OK;
-  }
   if (!strcmp(key, "attn_qg")) {
     if (value < 0 || value > 3) return FFD_ERR_INVALID;
     g_attn_qg = value;

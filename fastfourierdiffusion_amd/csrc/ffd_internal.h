@@ -115,7 +115,6 @@ extern int g_ffn_mb_override;
 extern int g_ffn_rem;
 extern int g_fuse_layer;
 extern int g_attn_impl;
-extern int g_dbg;
 extern int g_attn_qg;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]

@@ -278,8 +278,6 @@ hipError_t launch_linear(const float* X, const float* Wp, const float* bias, flo
   return hipGetLastError();
 }
 
-int g_dbg = 0;
-
 hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, float* out0, float* out1, float* out2,
                             int M, int nreg, int D, int L, int H, int hd, hipStream_t s) {
   if (M <= 0) return hipSuccess;
