@@ -134,6 +134,11 @@ int ffd_tune(const char* key, int value) {
     g_ffn_mb_override = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "ffn_stagger")) {
+    if (value < -1 || value > 4096) return FFD_ERR_INVALID;
+    g_ffn_stagger = value;
+    return FFD_OK;
+  }
   if (!strcmp(key, "ffn_rem")) {
     g_ffn_rem = value ? 1 : 0;
     return FFD_OK;

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
                                                   const float* __restrict__ W2r, const float* __restrict__ b2,
                                                   const float* __restrict__ gam, const float* __restrict__ bet,
-                                                  float* __restrict__ Y, int M, int F) {
+                                                  float* __restrict__ Y, int M, int F, int stagger) {
   constexpr int S = lds_stride(D);
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
@@ -109,6 +109,14 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   };
   load_w1(0);
   load_w2(0);
+  // De-phase the two waves that share a SIMD (they come from two workgroups that start together and
+  // run the same instruction stream, so without this they also stall together): the wave in the odd
+  // hardware wave slot starts its main loop `stagger` x 64 cycles late.
+  if (stagger > 0) {
+    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot in the SIMD
+    if (hwid & 1)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   for (int ci = 0; ci < nchunk; ++ci) {
     const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;  // clamped: the last prefetch is a harmless re-read
     // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   }
 }
 
+int g_ffn_stagger = -1;     // x64 cycles of start delay for the odd wave slot of each SIMD; -1 = heuristic (ffd_tune "ffn_stagger")
 int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
 int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
 
@@ -278,15 +287,19 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     const int target = 2 * 256;
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
+  // With two resident workgroups per CU and at least two rounds of tiles, de-phase the pair by about one
+  // prologue + epilogue so that one workgroup's non-MFMA phases run under the other's main loop
+  // (measured 469 -> 457 us on the 191488 x 72 x 2048 shape, tools/sweep_stagger.py).
+  const int stagger = g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0;
   dim3 block(256);
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
     if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,   \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F);                                                     \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger);                                             \
     else                                                                                                          \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,  \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F);                                                     \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger);                                             \
   } while (0)
   switch (mb) {
     case 8: FFD_LAUNCH_FFN(8); break;

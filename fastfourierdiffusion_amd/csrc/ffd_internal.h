@@ -113,6 +113,7 @@ hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights
                         int M, int D, int F, hipStream_t s);
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
+extern int g_ffn_stagger;
 extern int g_fuse_layer;
 extern int g_attn_impl;
 extern int g_attn_qg;

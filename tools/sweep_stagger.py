@@ -1,0 +1,16 @@
+import ctypes as C, os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, bench
+from fastfourierdiffusion_amd import _native as N
+model, sch, sd = bench.build_model(torch.device("cuda", 0), "ecg")
+ctx = model._ctx(); lib = ctx.lib
+vals = [0, 200, 400, 600, 800, 1000, 1200, 1600]
+res = {v: [] for v in vals}
+for rnd in range(4):
+    for v in vals:
+        assert lib.ffd_tune(b"ffn_stagger", v) == 0
+        ms = C.c_float()
+        N.check(lib.ffd_bench_ffn(ctx.handle, 512, 20, C.byref(ms), None), ctx.handle)
+        res[v].append(ms.value)
+for v in vals:
+    print(f"stagger={v:4d} (x64 cycles): median {statistics.median(res[v])*1e3:.1f} us  min {min(res[v])*1e3:.1f}")
