@@ -39,6 +39,11 @@ class FrescaCfg(C.Structure):
                 ("strategy", C.c_int32), ("num_steps", C.c_int32)]
 
 
+class CrfCaptureCfg(C.Structure):
+    _fields_ = [("ring", C.c_void_p), ("n_slots", C.c_int32), ("every", C.c_int32), ("last", C.c_void_p),
+                ("last_every", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CacheCfg(C.Structure):
     _fields_ = [("K", C.c_int32), ("R", C.c_int32)]
 
@@ -53,6 +58,10 @@ _F = C.POINTER(C.c_float)
 
 # name -> (restype, argtypes); must list every symbol include/ffd.h declares
 SIGNATURES = {
+    "ffd_freq_decompose": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P]),
+    "ffd_hermite_predict": (C.c_int, [_P, C.POINTER(C.c_double), C.c_double, C.c_int, _P, C.c_int, C.c_size_t, _P]),
+    "ffd_spectral_density": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ffd_cache_crf_capture": (C.c_int, [_P, C.POINTER(CrfCaptureCfg)]),
     "ffd_create": (C.c_int, [C.POINTER(_P), C.POINTER(ModelDesc), C.c_int]),
     "ffd_destroy": (None, [_P]),
     "ffd_last_error": (C.c_char_p, [_P]),

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -71,6 +72,8 @@ struct ffd_ctx {
   size_t ev_used = 0;
   // FreSca (sampler-level)
   bool fresca_on = false;
+  bool crf_cap_on = false;
+  ffd_crf_capture_cfg crf_cap{};
   ffd_fresca_cfg fcfg{};
   float *score2 = nullptr, *fwork = nullptr;
   int fwork_B = 0;
@@ -673,6 +676,94 @@ int ffd_fresca_disable(ffd_ctx* ctx) {
   return FFD_OK;
 }
 
+int ffd_freq_decompose(const float* x, float* low, float* high, int B, int L, int D, double low_freq_ratio,
+                       void* stream) {
+  if (!x || !low || !high || x == low || x == high || low == high || B < 1 || L < 2 || D < 1) return FFD_ERR_INVALID;
+  hipError_t e = launch_freq_decompose(x, low, high, B, L, D, low_freq_ratio, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+int ffd_spectral_density(const float* xf, float* out, int B, int L, int C, void* stream) {
+  if (!xf || !out || xf == out || B < 1 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  return launch_spectral_density(xf, out, B, L, C, (hipStream_t)stream) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
+// Hermite polynomials H_0..H_order at s (fourier.py:341-394: physicists' recurrence)
+static void hermite_row(double s, int order, double* H) {
+  H[0] = 1.0;
+  if (order >= 1) H[1] = 2.0 * s;
+  for (int n = 1; n < order; ++n) H[n + 1] = 2.0 * s * H[n] - 2.0 * n * H[n - 1];
+}
+
+int ffd_hermite_predict(const float* history, const double* timesteps, double target, int order, float* out, int K,
+                        size_t n, void* stream) {
+  if (!history || !timesteps || !out || K < 1 || K > 32 || order < 0 || order > 8) return FFD_ERR_INVALID;
+  float w[32] = {0};
+  double tmin = timesteps[0], tmax = timesteps[0];
+  for (int k = 1; k < K; ++k) tmin = std::min(tmin, timesteps[k]), tmax = std::max(tmax, timesteps[k]);
+  if (K < 2 || tmax == tmin) {
+    w[K - 1] = 1.f;  // fourier.py:416-428: not enough history -> last value
+  } else {
+    const int P = order + 1;
+    auto norm = [&](double t) {  // fourier.py:431-441, values held in fp32 tensors and clamped to [-1,1]
+      double v = (double)(float)(2.0 * (t - tmin) / (tmax - tmin) - 1.0);
+      return std::min(1.0, std::max(-1.0, v));
+    };
+    double Hm[32][9], Ht[9], A[9][18];
+    for (int k = 0; k < K; ++k) hermite_row(norm(timesteps[k]), order, Hm[k]);
+    hermite_row(norm(target), order, Ht);
+    // normal equations with ridge 1e-6 (fourier.py:462-466), inverted by Gauss-Jordan with partial pivoting
+    for (int i = 0; i < P; ++i)
+      for (int j = 0; j < P; ++j) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += Hm[k][i] * Hm[k][j];
+        A[i][j] = acc + (i == j ? 1e-6 : 0.0);
+        A[i][P + j] = i == j ? 1.0 : 0.0;
+      }
+    for (int c = 0; c < P; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < P; ++r)
+        if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+      if (A[piv][c] == 0.0) return FFD_ERR_INVALID;
+      if (piv != c)
+        for (int j = 0; j < 2 * P; ++j) std::swap(A[c][j], A[piv][j]);
+      const double inv = 1.0 / A[c][c];
+      for (int j = 0; j < 2 * P; ++j) A[c][j] *= inv;
+      for (int r = 0; r < P; ++r)
+        if (r != c) {
+          const double f = A[r][c];
+          if (f != 0.0)
+            for (int j = 0; j < 2 * P; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    // w_k = H_target . (HtH)^-1 . H_k   (prediction = sum_k w_k history_k, fourier.py:476-481)
+    for (int k = 0; k < K; ++k) {
+      double acc = 0.0;
+      for (int i = 0; i < P; ++i) {
+        double u = 0.0;
+        for (int j = 0; j < P; ++j) u += A[i][P + j] * Hm[k][j];
+        acc += Ht[i] * u;
+      }
+      w[k] = (float)acc;
+    }
+  }
+  return launch_weighted_sum(history, w, out, K, n, (hipStream_t)stream) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
+}
+
+int ffd_cache_crf_capture(ffd_ctx* ctx, const ffd_crf_capture_cfg* cfg) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (!cfg) {
+    ctx->crf_cap_on = false;
+    return FFD_OK;
+  }
+  if ((cfg->ring && (cfg->n_slots < 1 || cfg->every < 1)) || (cfg->last && cfg->last_every < 1))
+    return ctx->fail(FFD_ERR_INVALID, "bad CRF capture config (n_slots=%d every=%d last_every=%d)", cfg->n_slots,
+                     cfg->every, cfg->last_every);
+  ctx->crf_cap = *cfg;
+  ctx->crf_cap_on = cfg->ring || cfg->last;
+  return FFD_OK;
+}
+
 // ---------------------------------------------------------------------------
 // cache lifecycle
 // ---------------------------------------------------------------------------
@@ -782,7 +873,25 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
       ctx->stats.current_step = gstep;
       n_rec = ffd_host_gate(gstep, m.max_len, ctx->ccfg.K, ctx->ccfg.R);
     }
-    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, ctx->score, nullptr, B, n_rec, s))) return rc;
+    float* crf_dst = nullptr;
+    float* crf_copy = nullptr;
+    if (use_cache && ctx->crf_cap_on) {  // cache.update_crf(crf) with current_step == global step (sampler.py:70-73)
+      const ffd_crf_capture_cfg& cc = ctx->crf_cap;
+      const int gstep = global_step0 + j;
+      const size_t crf_n = (size_t)m.num_layers * m.max_len * d;
+      if (cc.ring && gstep % cc.every == 0) crf_dst = cc.ring + (size_t)((gstep / cc.every) % cc.n_slots) * crf_n;
+      if (cc.last && gstep % cc.last_every == 0) {
+        const int rest = n_run - 1 - j;  // is there a later qualifying step in this call?
+        const int to_next = cc.last_every - (gstep % cc.last_every);
+        if (to_next > rest) {
+          if (crf_dst) crf_copy = cc.last; else crf_dst = cc.last;
+        }
+      }
+    }
+    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, ctx->score, crf_dst, B, n_rec, s))) return rc;
+    if (crf_copy)
+      HIPCHECK(hipMemcpyAsync(crf_copy, crf_dst, sizeof(float) * (size_t)m.num_layers * m.max_len * d,
+                              hipMemcpyDeviceToDevice, s));
     if (use_cache) ctx->stats.current_step = i;  // sampler.py:73-74 (Q4)
     const double t = (double)timesteps[i];
     const float* score = ctx->score;

@@ -4,6 +4,8 @@
 //   - VP / VE reverse Euler-Maruyama step with on-device Philox4x32-10 noise
 //   - KV-table store
 // All HBM-bound: one pass over the data, coalesced, no re-reads.
+#include <algorithm>
+
 #include "ffd_internal.h"
 
 namespace ffd {
@@ -392,6 +394,27 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
   if (n <= 0) return hipSuccess;
   int blocks = cdiv(n * H * hd, 256);
   hipLaunchKernelGGL(k_kv_store, dim3(blocks), dim3(256), 0, s, k, v, kt, vt, L, H, hd, n);
+  return hipGetLastError();
+}
+
+// predict_hermite's last step (fourier.py:470-495): prediction = sum_k w_k * history[k]; the K weights come
+// from the (order+1)^2 normal equations solved on the host.
+struct WeightVec { float w[32]; };
+__global__ void k_weighted_sum(const float* __restrict__ hist, WeightVec wv, float* __restrict__ out, int K, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(wv.w[k], hist[(size_t)k * n + i], acc);
+    out[i] = acc;
+  }
+}
+
+hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* out, int K, size_t n, hipStream_t s) {
+  if (K < 1 || K > 32) return hipErrorInvalidValue;
+  if (n == 0) return hipSuccess;
+  WeightVec wv{};
+  for (int k = 0; k < K; ++k) wv.w[k] = w_host[k];
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_weighted_sum, dim3(blocks), dim3(256), 0, s, hist, wv, out, K, n);
   return hipGetLastError();
 }
 

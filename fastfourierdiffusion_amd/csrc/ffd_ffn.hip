@@ -289,7 +289,7 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   }
   // With two resident workgroups per CU and at least two rounds of tiles, de-phase the pair by about one
   // prologue + epilogue so that one workgroup's non-MFMA phases run under the other's main loop
-  // (measured 469 -> 457 us on the 191488 x 72 x 2048 shape, tools/sweep_stagger.py).
+  // (measured 469 -> 457 us on the 95744 x 72 x 2048 shape, tools/sweep_stagger.py).
   const int stagger = g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0;
   dim3 block(256);
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \

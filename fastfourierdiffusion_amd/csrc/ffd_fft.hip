@@ -13,6 +13,8 @@
 // k = 1 .. ceil(L/2)-1; scale 1/sqrt(L) both ways.
 #include <math.h>
 
+#include <algorithm>
+
 #include <map>
 #include <mutex>
 #include <vector>
@@ -329,6 +331,59 @@ hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L,
   }
   hipLaunchKernelGGL(k_fresca_apply, dim3(B, NGc), dim3(256), lds, s, in, out, W, plan, L, C, CG, rc_dev, rc_host, low,
                      high, sc * sc);
+  return hipGetLastError();
+}
+
+// frequency_decompose_fft (fourier.py:219-286): rfft along L, keep bins k < n_low for the low part and
+// k >= n_low for the high part, irfft each.  Same LDS-resident FFT -> mask -> inverse FFT kernel as FreSca
+// with factors (1,0) and (0,1); the tensor is (B, L, D) with D innermost, exactly the (B, L, C) layout.
+hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
+                                 hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (L < 2 || D < 1 || L > 4096) return hipErrorInvalidValue;
+  const float2* W = nullptr;
+  hipError_t e = get_twiddles(L, &W);
+  if (e != hipSuccess) return e;
+  FftPlan plan = make_plan(L);
+  int CG = D;
+  while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
+  const size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  const int nf = L / 2 + 1;
+  int n_low = (int)((double)nf * low_freq_ratio);  // fourier.py:249  max(1, int(n_freq * ratio))
+  if (n_low < 1) n_low = 1;
+  const float rc = (float)n_low - 0.5f;             // bins k <= rc  <=>  k < n_low
+  const float sc = (float)(1.0 / sqrt((double)L));
+  dim3 grid(B, cdiv(D, CG)), block(256);
+  hipLaunchKernelGGL(k_fresca_apply, grid, block, lds, s, in, low, W, plan, L, D, CG, (const int*)nullptr, rc, 1.f, 0.f,
+                     sc * sc);
+  hipLaunchKernelGGL(k_fresca_apply, grid, block, lds, s, in, high, W, plan, L, D, CG, (const int*)nullptr, rc, 0.f, 1.f,
+                     sc * sc);
+  return hipGetLastError();
+}
+
+// spectral_density on a packed spectrum (fourier.py:111-130): |X_k|^2 for k = 0..L/2; the imaginary part of
+// bin 0 (and of the Nyquist bin when L is even) is the implicit zero of the packed layout.
+__global__ void k_spectral_density(const float* __restrict__ xf, float* __restrict__ out, int B, int L, int C) {
+  const int nr = L / 2 + 1;
+  const size_t n = (size_t)B * nr * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t bk = i / C;
+    const int k = (int)(bk % nr);
+    const size_t b = bk / nr;
+    const float re = xf[(b * L + k) * C + c];
+    const bool has_im = k >= 1 && (nr + k - 1) < L;
+    const float im = has_im ? xf[(b * L + nr + k - 1) * C + c] : 0.f;
+    out[i] = re * re + im * im;
+  }
+}
+
+hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, int C, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const size_t n = (size_t)B * (L / 2 + 1) * C;
+  const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_spectral_density, dim3(blocks), dim3(256), 0, s, xf, out, B, L, C);
   return hipGetLastError();
 }
 

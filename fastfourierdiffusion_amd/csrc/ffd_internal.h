@@ -134,6 +134,10 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
 
 hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s);
+hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
+                                 hipStream_t s);
+hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, int C, hipStream_t s);
+hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* out, int K, size_t n, hipStream_t s);
 // FreSca spectral scaling of a (B,L,C) score; work: B*(L/2+1) + 1 floats; strategy 0 spatial, 1 energy
 hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,
                          double cutoff_ratio, int strategy, hipStream_t s);

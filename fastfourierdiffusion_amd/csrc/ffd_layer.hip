@@ -20,7 +20,7 @@ namespace ffd {
 
 template <int D>
 __global__ __launch_bounds__(256, 2) void k_layer(const float* __restrict__ attn, const float* __restrict__ xres,
-                                                  LayerWeights w, float* __restrict__ Y, NextProj nx, int M, int F) {
+                                                  LayerWeights w, float* __restrict__ Y, NextProj nx, int M, int F, int stagger) {
   constexpr int MB = 4;
   constexpr int R = 16 * MB;
   constexpr int S = lds_stride(D);
@@ -36,6 +36,11 @@ __global__ __launch_bounds__(256, 2) void k_layer(const float* __restrict__ attn
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rows_valid = min(R, M - m0);
 
+  if (stagger > 0) {  // de-phase the two workgroups of a CU (see k_ffn_ln)
+    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+    if (hwid & 1)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   // ------------------------------------------------------------------ prologue
   // out-proj weight fragments first: their L2 latency hides under the tile staging
   float4 wo[CT][G];
@@ -336,7 +341,7 @@ hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights
   dim3 grid(cdiv(M, 64)), block(256);
   switch (D) {
 #define X(d) \
-    case d: hipLaunchKernelGGL(k_layer<d>, grid, block, 0, s, attn, xres, w, Y, nx, M, F); break;
+    case d: hipLaunchKernelGGL(k_layer<d>, grid, block, 0, s, attn, xres, w, Y, nx, M, F, g_ffn_stagger > 0 ? g_ffn_stagger : 0); break;
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -140,6 +140,7 @@ class DiffusionSampler:
                     model.cache.reset()  # sampler.py:151-153
                     global_step = 0
                 use_cache = int(self.use_cache and model.cache is not None)
+                cap = self._crf_capture_begin(ctx, device) if use_cache else None
                 done = 0
                 while done < num_diffusion_steps:
                     n = num_diffusion_steps - done
@@ -157,13 +158,49 @@ class DiffusionSampler:
                                                   step_size, done, n, self.seed, sample_cursor, z_ptr, use_cache,
                                                   (global_step + done) if use_cache else 0, stream)
                     N.check(rc, ctx.handle, "ffd_sample_batch")
+                    if cap is not None:
+                        self._crf_capture_collect(cap, global_step + done, n, ts, done)
                     done += n
                 if use_cache:
+                    N.check(ctx.lib.ffd_cache_crf_capture(ctx.handle, None), ctx.handle, "ffd_cache_crf_capture")
                     global_step += num_diffusion_steps
                     model.cache.current_step = num_diffusion_steps - 1  # sampler.py:73-74 leaves step_idx
                 all_samples.append(X.cpu())
                 sample_cursor += batch_size
         return torch.cat(all_samples, dim=0)
+
+    # ------------------------------------------------------------------
+    # cache.update_crf (sampler.py:70-73) for the fused loop: the native loop writes the CRF of the steps the
+    # reference would have stored (E2CRFCache.update_crf, caching.py:474-522) into these buffers.
+    def _crf_capture_begin(self, ctx, device):
+        cache = self.score_model.cache
+        m = self.score_model
+        shape = (m.num_layers, m.max_len, m.d_model)
+        last = torch.empty(shape, device=device, dtype=torch.float32)
+        ring = None
+        if cache.use_freqca:
+            ring = torch.empty((max(1, int(cache.max_history)),) + shape, device=device, dtype=torch.float32)
+        cfg = N.CrfCaptureCfg(ring.data_ptr() if ring is not None else None, ring.shape[0] if ring is not None else 0,
+                              max(1, int(cache.freq_decomp_interval)) if ring is not None else 0, last.data_ptr(),
+                              1 if cache.use_freqca else max(1, int(cache.R)), 0)
+        N.check(ctx.lib.ffd_cache_crf_capture(ctx.handle, C.byref(cfg)), ctx.handle, "ffd_cache_crf_capture")
+        return {"last": last, "ring": ring, "cfg": cfg}
+
+    def _crf_capture_collect(self, cap, g0: int, n: int, ts: torch.Tensor, step0: int) -> None:
+        """Fold what ffd_sample_batch captured over global steps [g0, g0+n) into the cache object."""
+        cache = self.score_model.cache
+        cfg = cap["cfg"]
+        if any(g % cfg.last_every == 0 for g in range(g0, g0 + n)):
+            cache.crf_cache = cap["last"].clone()
+        if cap["ring"] is not None:
+            from ..utils.fourier import frequency_decompose_dct, frequency_decompose_fft
+
+            fn = frequency_decompose_fft if cache.freq_decomp == "fft" else frequency_decompose_dct
+            hits = [g for g in range(g0, g0 + n) if g % cfg.every == 0][-cfg.n_slots:]
+            for g in hits:  # only the newest max_history decompositions can survive in the history
+                slot = (g // cfg.every) % cfg.n_slots
+                low, high = fn(cap["ring"][slot], cache.low_freq_ratio)
+                cache._push_decomposition(low, high, float(ts[step0 + (g - g0)]))
 
     def sample_prior(self, batch_size: int, _sample_offset: int = 0) -> torch.Tensor:
         """sampler.py:217-228."""

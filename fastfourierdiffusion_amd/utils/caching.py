@@ -38,9 +38,11 @@ class E2CRFCache:
         self.freq_decomp_interval = freq_decomp_interval
         self.use_fresca_in_cache = use_fresca_in_cache
         self.fresca_adaptive_threshold = fresca_adaptive_threshold
-        if use_freqca:
-            raise NotImplementedError("use_freqca=True (FreqCa CRF decomposition) is a 'next' row of the scope table")
         self.crf_cache: Optional[torch.Tensor] = None
+        # FreqCa state (caching.py:103-106)
+        self.crf_low_cache: Optional[torch.Tensor] = None
+        self.crf_high_history: list = []
+        self.crf_timestep_history: list = []
         self.stats = {"recompute_count": 0, "cache_hit_count": 0}
         self.current_step = 0
         self._bound_model = None  # the score model whose native tables this object controls
@@ -48,6 +50,9 @@ class E2CRFCache:
     # caching.py:115-129
     def reset(self) -> None:
         self.crf_cache = None
+        self.crf_low_cache = None
+        self.crf_high_history = []
+        self.crf_timestep_history = []
         self.stats = {"recompute_count": 0, "cache_hit_count": 0}
         self.current_step = 0
         if self._bound_model is not None:
@@ -58,10 +63,41 @@ class E2CRFCache:
         n = N.lib().ffd_host_gate(int(step), int(self.max_len), int(self.K), int(self.R))
         return set(range(n))
 
-    # caching.py:459-484 (FreqCa branch not built)
+    # caching.py:459-522
     def update_crf(self, crf: torch.Tensor, timestep: Optional[float] = None) -> None:
-        if self.current_step % self.R == 0:
+        needs_crf = self.use_freqca or (self.current_step % self.R == 0)
+        if needs_crf:
             self.crf_cache = crf.detach()
+        if self.use_freqca:
+            should_decomp = self.current_step % self.freq_decomp_interval == 0 or self.current_step == 0
+            if should_decomp and needs_crf:
+                from .fourier import frequency_decompose_dct, frequency_decompose_fft
+
+                fn = frequency_decompose_fft if self.freq_decomp == "fft" else frequency_decompose_dct
+                crf_low, crf_high = fn(crf, self.low_freq_ratio)
+                self._push_decomposition(crf_low, crf_high, timestep)
+
+    def _push_decomposition(self, crf_low: torch.Tensor, crf_high: torch.Tensor, timestep: Optional[float]) -> None:
+        """caching.py:506-522: keep the low part, append the high part to the bounded history."""
+        self.crf_low_cache = crf_low.detach()
+        self.crf_high_history.append(crf_high.detach())
+        if timestep is not None:
+            self.crf_timestep_history.append(timestep)
+        if len(self.crf_high_history) > self.max_history:
+            self.crf_high_history.pop(0)
+            if self.crf_timestep_history:
+                self.crf_timestep_history.pop(0)
+
+    # caching.py:561-597
+    def predict_crf_freqca(self, t_val: float) -> Optional[torch.Tensor]:
+        if not self.use_freqca or self.crf_low_cache is None or len(self.crf_high_history) < 2:
+            return None
+        from .fourier import predict_hermite
+
+        crf_high_pred = predict_hermite(self.crf_high_history, self.crf_timestep_history, t_val, self.hermite_order)
+        if crf_high_pred is None:
+            return None
+        return self.crf_low_cache + crf_high_pred
 
     # caching.py:599-653
     def get_cache_stats(self) -> dict:
@@ -73,5 +109,10 @@ class E2CRFCache:
         ratio = hit_count / total if total > 0 else 0.0
         # cache_valid.float().mean(): after step 0 every row is valid -> capped at 0.99 (caching.py:625-628)
         cache_ratio = 0.99 if table else 0.0
-        return {"cache_hit_ratio": ratio, "cache_ratio": cache_ratio, "recompute_count": rc_count,
-                "cache_hit_count": hit_count, "current_step": self.current_step}
+        stats = {"cache_hit_ratio": ratio, "cache_ratio": cache_ratio, "recompute_count": rc_count,
+                 "cache_hit_count": hit_count, "current_step": self.current_step}
+        if self.use_freqca:  # caching.py:639-651
+            n = len(self.crf_high_history)
+            stats.update({"freq_decomp_count": n, "freq_decomp_skipped": max(0, self.current_step - n),
+                          "freq_decomp_ratio": n / self.current_step if self.current_step > 0 else 0.0})
+        return stats

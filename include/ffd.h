@@ -199,6 +199,41 @@ typedef struct {
 int ffd_fresca_enable(ffd_ctx* ctx, const ffd_fresca_cfg* cfg);
 int ffd_fresca_disable(ffd_ctx* ctx);
 
+/* ---- FreqCa helpers (E2CRFCache(use_freqca=True), caching.py:486-522,561-597) ---- */
+
+/* frequency_decompose_fft / frequency_decompose_dct (fourier.py:219-286; the dct variant returns the
+ * fft result, fourier.py:303): low = irfft(rfft(x)[k < n_low]), high = irfft(rfft(x)[k >= n_low]) along
+ * dim 1 of x (B, L, D), n_low = max(1, int((L/2+1) * low_freq_ratio)), ortho norm.  low/high must not
+ * alias x. */
+int ffd_freq_decompose(const float* x, float* low, float* high, int B, int L, int D, double low_freq_ratio,
+                       void* stream);
+
+/* predict_hermite (fourier.py:397-497): least-squares fit of Hermite polynomials H_0..H_order over the K
+ * history points (timesteps normalised to [-1,1], ridge 1e-6) evaluated at `target`.
+ * history: device (K, n) stacked tensors; timesteps: host K doubles; out: device n floats.
+ * K < 2 or equal timesteps return history[K-1] (fourier.py:416-428).  K <= 32, order <= 8. */
+int ffd_hermite_predict(const float* history, const double* timesteps, double target, int order, float* out, int K,
+                        size_t n, void* stream);
+
+/* spectral_density (fourier.py:97-131) of a PACKED spectrum xf (B, L, C) -> out (B, L/2+1, C);
+ * callers with time-domain input run ffd_dft first (apply_dft=True). */
+int ffd_spectral_density(const float* xf, float* out, int B, int L, int C, void* stream);
+
+/* CRF capture inside ffd_sample_batch (the reference's cache.update_crf call, sampler.py:70-73):
+ * on cached steps whose global step g satisfies g % every == 0 the (NL, L, d) CRF (score_models.py:181-194)
+ * is written to ring slot (g / every) % n_slots; `last` receives the CRF of the last step of each
+ * ffd_sample_batch call with g % last_every == 0 (E2CRFCache.crf_cache, caching.py:474-484).  Either pointer may
+ * be NULL; cfg == NULL switches capture off.  Buffers are caller-owned device memory. */
+typedef struct {
+  float* ring;
+  int32_t n_slots;
+  int32_t every;
+  float* last;
+  int32_t last_every;
+  int32_t reserved;
+} ffd_crf_capture_cfg;
+int ffd_cache_crf_capture(ffd_ctx* ctx, const ffd_crf_capture_cfg* cfg);
+
 /* ---- the sampling loop -------------------------------------------------- */
 
 /* E2CRFCache lifecycle used by DiffusionSampler (sampler.py:37-39,151-153):

@@ -109,3 +109,33 @@ FRESCA_DEFAULT = dict(low_scale=1.0, high_scale=1.5, cutoff_ratio=0.5, cutoff_st
 _STEPS = [0, 1, 2, 5, 10, 99, 100, 150, 200, 300, 499, 500, 501, 999, 1000, 1500]
 GATE_CASES = [(5, 10, 187, _STEPS), (0, 10, 187, _STEPS), (3, 100, 187, _STEPS), (1, 150, 187, _STEPS),
               (5, 500, 20, _STEPS), (200, 10, 187, _STEPS), (80, 10, 187, _STEPS), (5, 10, 8, _STEPS)]
+
+# FreqCa helpers (next row (f)2).  (name, B, L, D, seed, low_freq_ratio); B == 0 -> 2-D (L, D) input
+DECOMP_CASES = [
+    ("crf_ecg", 3, 187, 72, 81, 0.3),
+    ("crf_small", 2, 20, 24, 82, 0.3),
+    ("even", 3, 100, 16, 83, 0.5),
+    ("nlow1", 2, 64, 8, 84, 0.0),
+    ("two_d", 0, 50, 8, 85, 0.3),
+    ("syn", 2, 512, 72, 86, 0.25),
+]
+# (name, K, shape, order, timesteps, target, seed)
+HERMITE_CASES = [
+    ("h_order3", 6, (4, 20, 8), 3, [1.0, 0.9, 0.8, 0.7, 0.6, 0.5], 0.45, 91),
+    ("h_order2", 4, (20, 8), 2, [0.8, 0.6, 0.4, 0.2], 0.1, 92),
+    ("h_inside", 10, (2, 187, 72), 3, [1.0 - 0.01 * i for i in range(10)], 0.955, 93),
+    ("h_single", 1, (20, 8), 3, [0.5], 0.4, 94),
+    ("h_same_t", 3, (20, 8), 3, [0.5, 0.5, 0.5], 0.4, 95),
+]
+# (L, C, B, seed, apply_dft)
+DENSITY_CASES = [(187, 1, 4, 96, True), (100, 3, 2, 97, True), (251, 4, 2, 98, False), (512, 8, 2, 99, True)]
+# sampler runs with E2CRFCache(use_freqca=True): the cache object's FreqCa state after sample()
+FREQCA_TRAJ_CASES = [
+    dict(name="freqca_small", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=4, N=23,
+         use_cache=True, cache_kwargs=dict(use_freqca=True, freq_decomp="fft", freq_decomp_interval=4, max_history=3,
+                                           hermite_order=2, low_freq_ratio=0.3), wseed=42, zseed=65, t_pred=0.05),
+    dict(name="freqca_small_dct", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=3, num_samples=3, N=50,
+         use_cache=True, cache_kwargs=dict(use_freqca=True), wseed=42, zseed=66, t_pred=0.5),
+    dict(name="nofreqca_small_crf", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=3, num_samples=3, N=25,
+         use_cache=True, cache_kwargs={}, wseed=42, zseed=67, t_pred=None),
+]

@@ -200,6 +200,111 @@ def fresca(score: Tensor, low_scale: float = 1.0, high_scale: float = 1.0, cutof
 
 
 # --------------------------------------------------------------------------
+# FreqCa helpers + spectral density          (src/fdiff/utils/fourier.py)
+# --------------------------------------------------------------------------
+
+
+def frequency_decompose(x: Tensor, low_freq_ratio: float = 0.3) -> Tuple[Tensor, Tensor]:
+    """frequency_decompose_fft, fourier.py:219-286 (frequency_decompose_dct returns the
+    same thing, :303).  x (B,L,D) or (L,D); rfft/irfft restated as explicit fp64 DFT sums."""
+    was_2d = x.dim() == 2
+    if was_2d:
+        x = x.unsqueeze(0)
+    B, L, D = x.shape
+    nf = L // 2 + 1
+    n_low = max(1, int(nf * low_freq_ratio))  # :249
+    cr, ci = _dft_mats(L)
+    xd = x.detach().to(torch.float64).numpy()
+    re = np.einsum("kn,bnc->bkc", cr, xd)
+    im = np.einsum("kn,bnc->bkc", ci, xd)
+    w = np.full(nf, 2.0)
+    w[0] = 1.0
+    if L % 2 == 0:
+        w[-1] = 1.0
+    outs = []
+    for keep in (np.arange(nf) < n_low, np.arange(nf) >= n_low):
+        m = keep.astype(np.float64)[None, :, None]
+        o = np.einsum("kn,bkc->bnc", cr * w[:, None], re * m) + np.einsum("kn,bkc->bnc", ci * w[:, None], im * m)
+        o = torch.from_numpy(o.astype(np.float32))
+        outs.append(o.squeeze(0) if was_2d else o)
+    return outs[0], outs[1]
+
+
+def hermite_polynomials(s: Tensor, order: int) -> Tensor:
+    """fourier.py:341-394, 1-D s (K,) -> (order+1, K): closed forms up to H3, then the recurrence
+    H_{n+1} = 2s H_n - 2n H_{n-1} (same operation order as the reference: it matters for the fp32 rounding
+    that the ill-conditioned fit amplifies)."""
+    H = [torch.ones_like(s)]
+    if order >= 1:
+        H.append(2 * s)
+    if order >= 2:
+        H.append(4 * s ** 2 - 2)
+    if order >= 3:
+        H.append(8 * s ** 3 - 12 * s)
+    for n in range(3, order):
+        H.append(2 * s * H[n] - 2 * n * H[n - 1])
+    return torch.stack(H, 0)
+
+
+def predict_hermite(history: List[Tensor], ts: List[float], target: float, order: int = 2) -> Tensor:
+    """fourier.py:397-497: ridge least squares in the history's dtype (fp32)."""
+    if len(history) < 2:
+        return history[-1].clone()
+    t_min, t_max = min(ts), max(ts)
+    if t_max == t_min:
+        return history[-1].clone()
+    dtype = history[0].dtype
+    s_t = torch.clamp(torch.tensor(2 * (target - t_min) / (t_max - t_min) - 1, dtype=dtype), -1.0, 1.0)
+    s_h = torch.clamp(torch.tensor([2 * (t - t_min) / (t_max - t_min) - 1 for t in ts], dtype=dtype), -1.0, 1.0)
+    Hh = hermite_polynomials(s_h, order)            # (order+1, K)
+    Ht = hermite_polynomials(s_t.unsqueeze(0), order).squeeze(1)
+    Hm = Hh.T
+    inv = torch.linalg.inv(Hm.T @ Hm + torch.eye(order + 1, dtype=dtype) * 1e-6)
+    stack = torch.stack(history, 0)
+    flat = stack.reshape(len(history), -1)
+    coeffs = inv @ (Hm.T @ flat)
+    return (Ht @ coeffs).reshape(stack.shape[1:])
+
+
+def spectral_density(x: Tensor, apply_dft: bool = True) -> Tensor:
+    """fourier.py:97-131."""
+    L = x.shape[1]
+    xf = dft(x) if apply_dft else x
+    nr = math.ceil((L + 1) / 2)
+    re, im = xf[:, :nr, :], xf[:, nr:, :]
+    zero = torch.zeros(x.shape[0], 1, x.shape[2])
+    im = torch.cat((zero, im), 1)
+    if L % 2 == 0:
+        im = torch.cat((im, zero), 1)
+    return re ** 2 + im ** 2
+
+
+class FreqCaState:
+    """The FreqCa part of E2CRFCache.update_crf, caching.py:459-522."""
+
+    def __init__(self, R: int = 10, low_freq_ratio: float = 0.3, max_history: int = 10, interval: int = 10,
+                 use_freqca: bool = True):
+        self.R, self.ratio, self.max_history, self.interval, self.use_freqca = R, low_freq_ratio, max_history, interval, use_freqca
+        self.crf_cache = None
+        self.low = None
+        self.high_history: List[Tensor] = []
+        self.t_history: List[float] = []
+
+    def update(self, crf: Tensor, current_step: int, timestep: float) -> None:
+        needs = self.use_freqca or current_step % self.R == 0
+        if needs:
+            self.crf_cache = crf
+        if self.use_freqca and (current_step % self.interval == 0 or current_step == 0) and needs:
+            lo, hi = frequency_decompose(crf, self.ratio)
+            self.low = lo
+            self.high_history.append(hi)
+            self.t_history.append(timestep)
+            if len(self.high_history) > self.max_history:
+                self.high_history.pop(0)
+                self.t_history.pop(0)
+
+
+# --------------------------------------------------------------------------
 # M2 / M3 : positional + time encoders     (src/fdiff/models/transformer.py)
 # --------------------------------------------------------------------------
 
@@ -447,7 +552,7 @@ def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, n
            n_head: int, sde: str, sde_kwargs: Dict[str, float], fourier_noise_scaling: bool,
            num_samples: int, batch_size: int, num_steps: int, noise: Iterable[Tensor],
            use_cache: bool = False, K: int = 5, R: int = 10, eps: float = 1e-5,
-           fresca_kwargs: Optional[Dict] = None) -> Tensor:
+           fresca_kwargs: Optional[Dict] = None, freqca: Optional["FreqCaState"] = None) -> Tensor:
     """DiffusionSampler.sample, sampler.py:105-215, with the N(0,1) draws taken
     from ``noise`` in call order (one (B,L,C) tensor for the prior of each
     batch, then one per step) instead of torch's CPU generator.
@@ -468,6 +573,8 @@ def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, n
         if use_cache and b == 0:
             table = KVTable(num_layers, max_len)
             global_step = 0
+            if freqca is not None:  # cache.reset(), caching.py:115-129
+                freqca.__init__(freqca.R, freqca.ratio, freqca.max_history, freqca.interval, freqca.use_freqca)
         for i in range(num_steps):
             t_val = ts[i].item()
             t = torch.full((bs,), t_val, dtype=torch.float32)
@@ -475,7 +582,11 @@ def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, n
             if kind == "lstm":
                 score = lstm_score_forward(x, t, sd, num_layers)
             else:
-                score = score_forward(x, t, sd, num_layers, n_head, table if use_cache else None, rec)
+                if use_cache and freqca is not None:  # sampler.py:64-74: cache.update_crf(crf, timestep)
+                    score, crf = score_forward(x, t, sd, num_layers, n_head, table, rec, return_crf=True)
+                    freqca.update(crf, global_step, t_val)
+                else:
+                    score = score_forward(x, t, sd, num_layers, n_head, table if use_cache else None, rec)
             if fresca_kwargs is not None:  # sampler.py:79-93
                 score = fresca(score, timestep=t_val, num_steps=num_steps, **fresca_kwargs)
             z = next(noise)

@@ -91,10 +91,57 @@ def make_model(ns, c):
     return m, sch
 
 
+def gen_freqca(ns) -> None:
+    """G10: FreqCa helpers, spectral density and the cache's FreqCa state after sampling."""
+    from fdiff.utils import fourier as rf
+
+    g = {}
+    for (name, B, L, D, seed, ratio) in cases.DECOMP_CASES:
+        shape = (L, D) if B == 0 else (B, L, D)
+        x = torch.from_numpy(next(synthetic.noise_stream(shape, 1, seed)))
+        lo, hi = rf.frequency_decompose_fft(x, ratio)
+        lo2, hi2 = rf.frequency_decompose_dct(x, ratio)
+        assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+        g[f"decomp_{name}_low"], g[f"decomp_{name}_high"] = lo.numpy(), hi.numpy()
+    for (name, K, shape, order, ts, target, seed) in cases.HERMITE_CASES:
+        hist = [torch.from_numpy(a) for a in synthetic.noise_stream(shape, K, seed)]
+        g[f"hermite_{name}"] = rf.predict_hermite(hist, list(ts), target, order).numpy()
+    for (L, C, B, seed, apply) in cases.DENSITY_CASES:
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
+        g[f"density_L{L}_C{C}_{int(apply)}"] = rf.spectral_density(x, apply_dft=apply).numpy()
+    for c in cases.FREQCA_TRAJ_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+        nb = max(1, c["num_samples"] // B)
+        stream = synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"])
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=True,
+                                      cache_kwargs=dict(c["cache_kwargs"]))
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        cache = m.cache
+        name = c["name"]
+        g[f"{name}_out"] = out.numpy()
+        g[f"{name}_ts"] = sch.timesteps.numpy().copy()  # the grid this host's torch.linspace produced
+        g[f"{name}_crf_cache"] = cache.crf_cache.numpy()
+        if cache.use_freqca:
+            g[f"{name}_low"] = cache.crf_low_cache.numpy()
+            g[f"{name}_high_hist"] = torch.stack(cache.crf_high_history, 0).numpy()
+            g[f"{name}_t_hist"] = np.array(cache.crf_timestep_history, dtype=np.float64)
+            st = cache.get_cache_stats()
+            g[f"{name}_stats"] = np.array([st["freq_decomp_count"], st["freq_decomp_skipped"], st["current_step"]],
+                                          dtype=np.int64)
+            g[f"{name}_pred"] = cache.predict_crf_freqca(c["t_pred"]).numpy()
+        print(name, out.shape, len(cache.crf_high_history))
+    np.savez_compressed(os.path.join(OUT, "g10_freqca.npz"), **g)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
+    if "--only-freqca" in sys.argv:  # regenerate just G10 (the 1000-step trajectories take minutes)
+        gen_freqca(ns)
+        return
     meta = {"torch": torch.__version__}
 
     # ---- G1: dft / idft -------------------------------------------------
@@ -217,6 +264,8 @@ def main() -> None:
         g[f"gate_K{K}_R{R}_L{L}_sizes"] = sizes
         g[f"gate_K{K}_R{R}_L{L}_first"] = first
     np.savez_compressed(os.path.join(OUT, "g9_gate.npz"), **g)
+
+    gen_freqca(ns)
 
     with open(os.path.join(OUT, "META.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from the unmodified reference at /root/reference\n")

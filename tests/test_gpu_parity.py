@@ -449,3 +449,84 @@ def test_cache_on_off_and_stats_q5(ffd):
     assert m.cache.get_cache_stats()["cache_hit_count"] == 0  # Q5: layers still feed the first cache
     with pytest.raises(TypeError):  # README's random_probe_ratio is not a kwarg (Q6)
         DiffusionSampler(m, 2, use_cache=True, cache_kwargs={"random_probe_ratio": 0.1})
+
+
+# ------------------------------------------ FreqCa helpers (scope row (f)2/(f)3) ----
+TOL_HERMITE = 2e-3  # the reference inverts ridge-regularised normal equations in fp32: conditioning-limited
+
+
+@pytest.mark.parametrize("case", cases.DECOMP_CASES, ids=lambda c: c[0])
+def test_freq_decompose_golden(ffd, golden, case):
+    from fastfourierdiffusion_amd.utils.fourier import frequency_decompose_dct, frequency_decompose_fft
+
+    name, B, L, D, seed, ratio = case
+    shape = (L, D) if B == 0 else (B, L, D)
+    x = torch.from_numpy(next(synthetic.noise_stream(shape, 1, seed))).cuda()
+    lo, hi = frequency_decompose_fft(x, ratio)
+    g = golden["g10_freqca"]
+    assert tuple(lo.shape) == g[f"decomp_{name}_low"].shape and lo.is_cuda
+    assert rel_err(lo.cpu(), g[f"decomp_{name}_low"]) < TOL_OP
+    assert rel_err(hi.cpu(), g[f"decomp_{name}_high"]) < TOL_OP
+    lo2, hi2 = frequency_decompose_dct(x, ratio)  # fourier.py:303: the dct entry returns the fft result
+    assert torch.equal(lo, lo2) and torch.equal(hi, hi2)
+
+
+@pytest.mark.parametrize("case", cases.HERMITE_CASES, ids=lambda c: c[0])
+def test_hermite_golden(ffd, golden, case):
+    from fastfourierdiffusion_amd.utils.fourier import predict_hermite
+
+    name, K, shape, order, ts, target, seed = case
+    hist = [torch.from_numpy(a).cuda() for a in synthetic.noise_stream(shape, K, seed)]
+    y = predict_hermite(hist, list(ts), target, order)
+    assert rel_err(y.cpu(), golden["g10_freqca"][f"hermite_{name}"]) < TOL_HERMITE
+
+
+@pytest.mark.parametrize("case", cases.DENSITY_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
+def test_spectral_density_golden(ffd, golden, case):
+    from fastfourierdiffusion_amd.utils.fourier import spectral_density
+
+    L, C, B, seed, apply = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed))).cuda()
+    y = spectral_density(x, apply_dft=apply)
+    assert rel_err(y.cpu(), golden["g10_freqca"][f"density_L{L}_C{C}_{int(apply)}"]) < 2 * TOL_OP
+
+
+@pytest.mark.parametrize("c", cases.FREQCA_TRAJ_CASES, ids=lambda c: c["name"])
+@pytest.mark.parametrize("chunk", [7, 1000])
+def test_freqca_state_golden(ffd, golden, c, chunk):
+    """E2CRFCache(use_freqca=True) state after DiffusionSampler.sample: CRF slot, low part, high history,
+    timestep history, stats and predict_crf_freqca -- with the loop run in 7-step chunks and in one call."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    m, sch = make_model(ffd, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    g, name = golden["g10_freqca"], c["name"]
+    sampler = DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=True, cache_kwargs=dict(c["cache_kwargs"]),
+                               z_chunk_steps=chunk)
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    ts_golden = torch.from_numpy(g[f"{name}_ts"].copy())
+    orig = sch.set_timesteps
+
+    def pinned(n):
+        orig(n)
+        sch.timesteps = ts_golden
+        sch.step_size = ts_golden[0] - ts_golden[1]
+
+    sch.set_timesteps = pinned
+    out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+    cache = m.cache
+    assert rel_err(out, g[f"{name}_out"]) < TOL_TRAJ
+    assert rel_err(cache.crf_cache.cpu(), g[f"{name}_crf_cache"]) < TOL_TRAJ
+    st = cache.get_cache_stats()
+    if cache.use_freqca:
+        assert rel_err(cache.crf_low_cache.cpu(), g[f"{name}_low"]) < TOL_TRAJ
+        hist = torch.stack([h.cpu() for h in cache.crf_high_history], 0)
+        assert tuple(hist.shape) == g[f"{name}_high_hist"].shape
+        assert rel_err(hist, g[f"{name}_high_hist"]) < TOL_TRAJ
+        np.testing.assert_array_equal(np.array(cache.crf_timestep_history, dtype=np.float64), g[f"{name}_t_hist"])
+        assert [st["freq_decomp_count"], st["freq_decomp_skipped"], st["current_step"]] == g[f"{name}_stats"].tolist()
+        pred = cache.predict_crf_freqca(c["t_pred"])
+        assert rel_err(pred.cpu(), g[f"{name}_pred"]) < TOL_HERMITE
+    else:
+        assert "freq_decomp_count" not in st and cache.predict_crf_freqca(0.5) is None

@@ -166,3 +166,63 @@ def test_gate_golden(golden, case):
     first = [(O.gate(s, L, K, R)[:1] or [-1])[0] for s in steps]
     np.testing.assert_array_equal(sizes, g[f"gate_K{K}_R{R}_L{L}_sizes"])
     np.testing.assert_array_equal(first, g[f"gate_K{K}_R{R}_L{L}_first"])
+
+
+# ---- FreqCa helpers, spectral density, FreqCa cache state (scope row (f)2/(f)3) ----
+# Hermite prediction solves ridge-regularised normal equations in fp32 inside the reference
+# (torch.linalg.inv); its result is conditioning-limited, hence the looser tolerance.
+TOL_HERMITE = 2e-3
+
+
+@pytest.mark.parametrize("case", cases.DECOMP_CASES, ids=lambda c: c[0])
+def test_freq_decompose_golden(golden, case):
+    name, B, L, D, seed, ratio = case
+    shape = (L, D) if B == 0 else (B, L, D)
+    x = torch.from_numpy(next(synthetic.noise_stream(shape, 1, seed)))
+    lo, hi = O.frequency_decompose(x, ratio)
+    g = golden["g10_freqca"]
+    assert lo.shape == g[f"decomp_{name}_low"].shape
+    assert rel_err(lo, g[f"decomp_{name}_low"]) < TOL_KERNEL
+    assert rel_err(hi, g[f"decomp_{name}_high"]) < TOL_KERNEL
+    assert rel_err(lo + hi, x) < 4 * TOL_KERNEL  # the two parts partition the spectrum
+
+
+@pytest.mark.parametrize("case", cases.HERMITE_CASES, ids=lambda c: c[0])
+def test_hermite_golden(golden, case):
+    name, K, shape, order, ts, target, seed = case
+    hist = [torch.from_numpy(a) for a in synthetic.noise_stream(shape, K, seed)]
+    y = O.predict_hermite(hist, list(ts), target, order)
+    assert rel_err(y, golden["g10_freqca"][f"hermite_{name}"]) < TOL_HERMITE
+
+
+@pytest.mark.parametrize("case", cases.DENSITY_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
+def test_spectral_density_golden(golden, case):
+    L, C, B, seed, apply = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
+    assert rel_err(O.spectral_density(x, apply), golden["g10_freqca"][f"density_L{L}_C{C}_{int(apply)}"]) < 2 * TOL_KERNEL
+
+
+@pytest.mark.parametrize("c", cases.FREQCA_TRAJ_CASES, ids=lambda c: c["name"])
+def test_freqca_state_golden(golden, c):
+    sd = make_sd(c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    ck = c["cache_kwargs"]
+    st = O.FreqCaState(R=ck.get("R", 10), low_freq_ratio=ck.get("low_freq_ratio", 0.3),
+                       max_history=ck.get("max_history", 10), interval=ck.get("freq_decomp_interval", 10),
+                       use_freqca=ck.get("use_freqca", False))
+    out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=c["sde"],
+                   sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"], num_samples=c["num_samples"],
+                   batch_size=B, num_steps=N, noise=noise, use_cache=True, K=ck.get("K", 5), R=ck.get("R", 10),
+                   freqca=st)
+    g, name = golden["g10_freqca"], c["name"]
+    assert rel_err(out, g[f"{name}_out"]) < TOL_TRAJ
+    assert rel_err(st.crf_cache, g[f"{name}_crf_cache"]) < TOL_TRAJ
+    if st.use_freqca:
+        assert rel_err(st.low, g[f"{name}_low"]) < TOL_TRAJ
+        assert rel_err(torch.stack(st.high_history, 0), g[f"{name}_high_hist"]) < TOL_TRAJ
+        np.testing.assert_allclose(np.array(st.t_history), g[f"{name}_t_hist"], rtol=0, atol=0)
+        assert len(st.high_history) == int(g[f"{name}_stats"][0])
+        pred = st.low + O.predict_hermite(st.high_history, st.t_history, c["t_pred"], ck.get("hermite_order", 3))
+        assert rel_err(pred, g[f"{name}_pred"]) < TOL_HERMITE
