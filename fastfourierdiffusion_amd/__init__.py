@@ -4,10 +4,10 @@ A drop-in for the *sampling* surface of NoakLiu/FastFourierDiffusion (``fdiff``)
 sub-modules mirror the reference's import paths
 
     fdiff.sampling.sampler.DiffusionSampler      -> .sampling.sampler
-    fdiff.models.score_models.{ScoreModule,LSTMScoreModule} -> .models.score_models
+    fdiff.models.score_models.{ScoreModule,LSTMScoreModule,MLPScoreModule} -> .models.score_models
     fdiff.schedulers.sde.{SDE,VPScheduler,VEScheduler}      -> .schedulers.sde
     fdiff.utils.caching.E2CRFCache               -> .utils.caching
-    fdiff.utils.fourier.{dft,idft}               -> .utils.fourier
+    fdiff.utils.fourier.{dft,idft,spectral_density,frequency_decompose_*,predict_hermite} -> .utils.fourier
     fdiff.utils.dataclasses.DiffusableBatch      -> .utils.dataclasses
 
 and ``install_as_fdiff()`` registers them under the ``fdiff.*`` names so that existing
@@ -59,6 +59,7 @@ def __getattr__(name):  # lazy top-level conveniences
         "DiffusionSampler": ("fastfourierdiffusion_amd.sampling.sampler", "DiffusionSampler"),
         "ScoreModule": ("fastfourierdiffusion_amd.models.score_models", "ScoreModule"),
         "LSTMScoreModule": ("fastfourierdiffusion_amd.models.score_models", "LSTMScoreModule"),
+        "MLPScoreModule": ("fastfourierdiffusion_amd.models.score_models", "MLPScoreModule"),
         "VPScheduler": ("fastfourierdiffusion_amd.schedulers.sde", "VPScheduler"),
         "VEScheduler": ("fastfourierdiffusion_amd.schedulers.sde", "VEScheduler"),
         "E2CRFCache": ("fastfourierdiffusion_amd.utils.caching", "E2CRFCache"),

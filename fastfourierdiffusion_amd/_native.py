@@ -14,7 +14,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libffd.so")
 
-FFD_MODEL_TRANSFORMER, FFD_MODEL_LSTM = 0, 1
+FFD_MODEL_TRANSFORMER, FFD_MODEL_LSTM, FFD_MODEL_MLP = 0, 1, 2
 FFD_SDE_VP, FFD_SDE_VE = 0, 1
 
 

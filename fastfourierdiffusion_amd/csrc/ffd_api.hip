@@ -225,8 +225,12 @@ int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
   const ffd_model_desc& m = ctx->desc;
   if (m.n_channels < 1 || m.max_len < 1 || m.num_layers < 1)
     return ctx->fail(FFD_ERR_INVALID, "bad shape: C=%d L=%d NL=%d", m.n_channels, m.max_len, m.num_layers);
-  if (!d_supported(m.d_model))
+  if (m.kind == FFD_MODEL_MLP) {
+    if (m.d_model < 1 || m.dim_feedforward < 1)
+      return ctx->fail(FFD_ERR_INVALID, "mlp: d_model=%d d_mlp=%d", m.d_model, m.dim_feedforward);
+  } else if (!d_supported(m.d_model)) {
     return ctx->fail(FFD_ERR_UNSUPPORTED, "d_model=%d: this build has kernels for d_model in {8, 16, 24, 32, 48, 60, 64, 72}", m.d_model);
+  }
   if (m.kind == FFD_MODEL_TRANSFORMER) {
     if (m.n_head < 1 || m.d_model % m.n_head != 0)
       return ctx->fail(FFD_ERR_INVALID, "d_model=%d not divisible by n_head=%d", m.d_model, m.n_head);
@@ -235,7 +239,7 @@ int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
     if (m.dim_feedforward < 64 || m.dim_feedforward % 64 != 0)
       return ctx->fail(FFD_ERR_UNSUPPORTED, "dim_feedforward=%d must be a positive multiple of 64", m.dim_feedforward);
     if (m.max_len > 512) return ctx->fail(FFD_ERR_UNSUPPORTED, "max_len=%d > 512 (attention kernel limit)", m.max_len);
-  } else if (m.kind != FFD_MODEL_LSTM) {
+  } else if (m.kind != FFD_MODEL_LSTM && m.kind != FFD_MODEL_MLP) {
     return ctx->fail(FFD_ERR_UNSUPPORTED, "model kind %d", m.kind);
   }
   if (m.sde != FFD_SDE_VP && m.sde != FFD_SDE_VE) return ctx->fail(FFD_ERR_UNSUPPORTED, "sde kind %d", m.sde);
@@ -278,10 +282,11 @@ static void expected_weights(const ffd_model_desc& m, std::vector<std::pair<std:
   out.push_back({"time_encoder.W", (d + 1) / 2});
   out.push_back({"time_encoder.dense.weight", d * d});
   out.push_back({"time_encoder.dense.bias", d});
-  out.push_back({"embedder.weight", d * C});
+  const size_t io = m.kind == FFD_MODEL_MLP ? L * C : C;  // the MLP embeds the flattened series (score_models.py:392-397)
+  out.push_back({"embedder.weight", d * io});
   out.push_back({"embedder.bias", d});
-  out.push_back({"unembedder.weight", C * d});
-  out.push_back({"unembedder.bias", C});
+  out.push_back({"unembedder.weight", io * d});
+  out.push_back({"unembedder.bias", io});
   for (int i = 0; i < m.num_layers; ++i) {
     char p[64];
     if (m.kind == FFD_MODEL_TRANSFORMER) {
@@ -299,6 +304,14 @@ static void expected_weights(const ffd_model_desc& m, std::vector<std::pair<std:
       out.push_back({s + "norm1.bias", d});
       out.push_back({s + "norm2.weight", d});
       out.push_back({s + "norm2.bias", d});
+    } else if (m.kind == FFD_MODEL_MLP) {
+      // torchvision.ops.MLP(d, [d_mlp, d]) = Sequential(Linear, ReLU, Dropout, Linear, Dropout): indices 0 and 3
+      snprintf(p, sizeof p, "backbone.%d.", i);
+      std::string s(p);
+      out.push_back({s + "0.weight", F * d});
+      out.push_back({s + "0.bias", F});
+      out.push_back({s + "3.weight", d * F});
+      out.push_back({s + "3.bias", d});
     } else {
       snprintf(p, sizeof p, "backbone.%d.", i);
       std::string s(p);
@@ -390,7 +403,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       lw.w2p = pk.w2p;
       lw.w2r = pk.w2r;
     }
-  } else {
+  } else if (m.kind == FFD_MODEL_LSTM) {
     const bool first = ctx->lstm.empty();
     if (first) ctx->lstm.resize(m.num_layers);
     for (int i = 0; i < m.num_layers; ++i) {
@@ -430,7 +443,10 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->h0, M * d))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->score, M * m.n_channels))) return rc;
-  if (m.kind == FFD_MODEL_TRANSFORMER) {
+  if (m.kind == FFD_MODEL_MLP) {
+    if ((rc = dev_alloc(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
+    if ((rc = dev_alloc(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
+  } else if (m.kind == FFD_MODEL_TRANSFORMER) {
     if ((rc = dev_alloc(ctx, &ctx->h1, M * d))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->qkv, M * 3 * d))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->attn, M * d))) return rc;
@@ -448,6 +464,27 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
                         int n_rec, hipStream_t s) {
   const ffd_model_desc& m = ctx->desc;
   const int L = m.max_len, C = m.n_channels, d = m.d_model, M = B * L;
+  if (m.kind == FFD_MODEL_MLP) {  // MLPScoreModule.forward, score_models.py:406-440
+    const int io = L * C, F = m.dim_feedforward;
+    // flatten "b t c -> b (t c)" is the memory layout already; time encoding is one (d,) vector per step
+    HIPCHECK(launch_dense(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, temb, nullptr, ctx->h0, B, d,
+                          io, 0, s));
+    float* cur = ctx->h0;
+    float* alt = ctx->h1;
+    for (int i = 0; i < m.num_layers; ++i) {
+      char p[64];
+      snprintf(p, sizeof p, "backbone.%d.", i);
+      const std::string pre(p);
+      HIPCHECK(launch_dense(cur, ctx->raw[pre + "0.weight"].p, ctx->raw[pre + "0.bias"].p, nullptr, nullptr, ctx->qkv,
+                            B, F, d, 1, s));
+      HIPCHECK(launch_dense(ctx->qkv, ctx->raw[pre + "3.weight"].p, ctx->raw[pre + "3.bias"].p, nullptr, cur, alt, B,
+                            d, F, 0, s));  // X + layer(X)
+      std::swap(cur, alt);
+    }
+    HIPCHECK(launch_dense(cur, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, nullptr, nullptr,
+                          score_out, B, io, d, 0, s));
+    return FFD_OK;
+  }
   if (m.kind == FFD_MODEL_LSTM) {
     HIPCHECK(launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb, ctx->h0, B, L,
                           C, d, s));
@@ -920,6 +957,7 @@ double ffd_flops_per_sample_step(const ffd_ctx* ctx, int cache_hit) {
   const ffd_model_desc& m = ctx->desc;
   const double L = m.max_len, d = m.d_model, C = m.n_channels, NL = m.num_layers, F = m.dim_feedforward;
   if (m.kind == FFD_MODEL_LSTM) return NL * 2.0 * L * (2.0 * 4.0 * d * d) + 4.0 * L * C * d + 2.0 * d * d;
+  if (m.kind == FFD_MODEL_MLP) return NL * 4.0 * d * F + 4.0 * L * C * d + 2.0 * d * d;
   double per_layer = 2.0 * L * d * 3.0 * d + 2.0 * L * L * d + 2.0 * L * L * d + 2.0 * L * d * d + 4.0 * L * d * F;
   if (cache_hit) per_layer -= 2.0 * L * d * 2.0 * d;
   return NL * per_layer + 4.0 * L * C * d + 2.0 * d * d;

@@ -133,6 +133,8 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
 
+hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,
+                        int M, int N, int K, int relu, hipStream_t s);
 hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s);
 hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
                                  hipStream_t s);

@@ -289,3 +289,42 @@ class LSTMScoreModule(ScoreModule):
     def forward(self, batch: DiffusableBatch) -> torch.Tensor:  # type: ignore[override]
         """score_models.py:486-511 (no recompute_tokens / caching, Q9)."""
         return super().forward(batch)
+
+
+class MLPScoreModule(ScoreModule):
+    """MLP score model (score_models.py:363-440): the flattened series (L*C) is embedded to d_model,
+    ``x <- x + MLP_l(x)`` for ``num_layers`` blocks d -> d_mlp -> d (ReLU), then unembedded to L*C.
+    The reference's block is ``torchvision.ops.MLP`` (= Sequential(Linear, ReLU, Dropout, Linear, Dropout));
+    the same container layout is built here so the state_dict keys (``backbone.{i}.0.*``, ``backbone.{i}.3.*``)
+    match."""
+
+    _kind = N.FFD_MODEL_MLP
+
+    def __init__(self, n_channels: int, max_len: int, noise_scheduler: SDE, fourier_noise_scaling: bool = True,
+                 d_model: int = 72, d_mlp: int = 512, num_layers: int = 3, num_training_steps: int = 1000,
+                 lr_max: float = 1e-3, likelihood_weighting: bool = False) -> None:
+        self.d_mlp = d_mlp  # plain attribute: needed by _build_backbone, which ScoreModule.__init__ calls
+        super().__init__(n_channels=n_channels, max_len=max_len, noise_scheduler=noise_scheduler,
+                         fourier_noise_scaling=fourier_noise_scaling, d_model=d_model, num_layers=num_layers, n_head=1,
+                         num_training_steps=num_training_steps, lr_max=lr_max,
+                         likelihood_weighting=likelihood_weighting)
+
+    def _build_backbone(self) -> None:
+        # replay the reference's construction order (a discarded 1-head TransformerEncoder from
+        # ScoreModule.__init__, then embedder / unembedder / blocks, score_models.py:377-403)
+        layer = nn.TransformerEncoderLayer(d_model=self.d_model, nhead=1, batch_first=True)
+        nn.TransformerEncoder(encoder_layer=layer, num_layers=self.num_layers)
+        io = self.max_len * self.n_channels
+        self.embedder = nn.Linear(in_features=io, out_features=self.d_model)
+        self.unembedder = nn.Linear(in_features=self.d_model, out_features=io)
+        self.backbone = nn.ModuleList([
+            nn.Sequential(nn.Linear(self.d_model, self.d_mlp), nn.ReLU(), nn.Dropout(0.1),
+                          nn.Linear(self.d_mlp, self.d_model), nn.Dropout(0.1))
+            for _ in range(self.num_layers)
+        ])
+        self.pos_encoder = None
+        self.dim_feedforward = self.d_mlp
+
+    def forward(self, batch: DiffusableBatch) -> torch.Tensor:  # type: ignore[override]
+        """score_models.py:406-440 (no recompute_tokens / caching, Q9)."""
+        return super().forward(batch)

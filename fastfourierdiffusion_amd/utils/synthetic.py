@@ -77,6 +77,26 @@ def lstm_state_dict(n_channels: int, max_len: int, d_model: int = 72, num_layers
     return sd
 
 
+def mlp_state_dict(n_channels: int, max_len: int, d_model: int = 72, d_mlp: int = 512, num_layers: int = 3,
+                   seed: int = 42) -> Dict[str, np.ndarray]:
+    """State dict with the reference MLPScoreModule's parameter names (score_models.py:392-405; the blocks are
+    torchvision.ops.MLP(d, [d_mlp, d]) = Sequential(Linear, ReLU, Dropout, Linear, Dropout): indices 0 and 3)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    d, io = d_model, max_len * n_channels
+    sd = _common(rng, n_channels, max_len, d, with_pos=False)
+    sd["embedder.weight"] = _uniform(rng, (d, io), 1 / math.sqrt(io))
+    sd["embedder.bias"] = _uniform(rng, (d,), 1 / math.sqrt(io))
+    sd["unembedder.weight"] = _uniform(rng, (io, d), 1 / math.sqrt(d))
+    sd["unembedder.bias"] = _uniform(rng, (io,), 1 / math.sqrt(d))
+    for i in range(num_layers):
+        p = f"backbone.{i}."
+        sd[p + "0.weight"] = _uniform(rng, (d_mlp, d), 1 / math.sqrt(d))
+        sd[p + "0.bias"] = _uniform(rng, (d_mlp,), 1 / math.sqrt(d))
+        sd[p + "3.weight"] = _uniform(rng, (d, d_mlp), 1 / math.sqrt(d_mlp))
+        sd[p + "3.bias"] = _uniform(rng, (d,), 1 / math.sqrt(d_mlp))
+    return sd
+
+
 def noise_stream(shape, count: int, seed: int):
     """``count`` independent N(0,1) fp32 arrays of ``shape`` (injected-noise parity runs)."""
     rng = np.random.Generator(np.random.PCG64(seed))

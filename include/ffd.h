@@ -44,21 +44,21 @@ typedef enum {
   FFD_ERR_NOMEM = -5
 } ffd_status;
 
-enum { FFD_MODEL_TRANSFORMER = 0, FFD_MODEL_LSTM = 1 };
+enum { FFD_MODEL_TRANSFORMER = 0, FFD_MODEL_LSTM = 1, FFD_MODEL_MLP = 2 };
 enum { FFD_SDE_VP = 0, FFD_SDE_VE = 1 };
 
 /* Model + scheduler hyper-parameters.
- * Replaces the constructor arguments of ScoreModule / LSTMScoreModule
- * (src/fdiff/models/score_models.py:25-37, 444-455) and of VPScheduler /
+ * Replaces the constructor arguments of ScoreModule / LSTMScoreModule / MLPScoreModule
+ * (src/fdiff/models/score_models.py:25-37, 444-455, 364-376) and of VPScheduler /
  * VEScheduler (src/fdiff/schedulers/sde.py:91-97, 169-175). */
 typedef struct {
   int32_t kind;            /* FFD_MODEL_* */
   int32_t n_channels;      /* C */
   int32_t max_len;         /* L */
-  int32_t d_model;         /* d   (8, 16, 24, 32, 48, 60, 64 or 72 in this build; d / n_head in {2,3,4,5,6,8}) */
+  int32_t d_model;         /* d   (8, 16, 24, 32, 48, 60, 64 or 72 in this build; d / n_head in {2,3,4,5,6,8}; any d for mlp) */
   int32_t n_head;          /* H   (ignored for lstm) */
   int32_t num_layers;      /* NL */
-  int32_t dim_feedforward; /* F   (PyTorch default 2048, score_models.py:61-63); multiple of 64 */
+  int32_t dim_feedforward; /* F   (PyTorch default 2048, score_models.py:61-63); multiple of 64.  mlp: d_mlp (any >= 1) */
   int32_t sde;             /* FFD_SDE_* */
   double sde_a;            /* VP: beta_min   | VE: sigma_min */
   double sde_b;            /* VP: beta_max   | VE: sigma_max */

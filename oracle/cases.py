@@ -139,3 +139,12 @@ FREQCA_TRAJ_CASES = [
     dict(name="nofreqca_small_crf", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=3, num_samples=3, N=25,
          use_cache=True, cache_kwargs={}, wseed=42, zseed=67, t_pred=None),
 ]
+
+# MLPScoreModule (scope row (f)3).  PARITY UNPINNED against the reference: torchvision.ops.MLP is not importable here,
+# so no golden exists; the product is checked against the oracle restatement (oracle.mlp_score_forward) only.
+MLP_CASES = [
+    dict(name="refunit_mlp", kind="mlp", d=8, d_mlp=512, NL=2, L=20, C=3, H=1, B=5, wseed=49, xseed=39),    # tests/test_score_models.py:13-19,36
+    dict(name="ecg_mlp", kind="mlp", d=72, d_mlp=1024, NL=10, L=187, C=1, H=1, B=4, wseed=50, xseed=40),       # cmd/conf/score_model/mlp.yaml
+    dict(name="nasa_mlp", kind="mlp", d=72, d_mlp=512, NL=3, L=251, C=4, H=1, B=7, wseed=51, xseed=41),      # L*C % 4 == 0
+    dict(name="odd_mlp", kind="mlp", d=13, d_mlp=70, NL=1, L=9, C=2, H=1, B=33, wseed=52, xseed=42),         # ragged everything
+]

@@ -548,6 +548,23 @@ def lstm_score_forward(x: Tensor, t: Tensor, sd: Dict[str, Tensor], num_layers: 
 # --------------------------------------------------------------------------
 
 
+def mlp_score_forward(x: Tensor, t: Tensor, sd: Dict[str, Tensor], num_layers: int) -> Tensor:
+    """MLPScoreModule.forward, score_models.py:406-440.  PARITY UNPINNED: the reference's block is
+    torchvision.ops.MLP, which is not importable in this image; restated from its documented structure
+    (Linear -> ReLU -> Dropout -> Linear -> Dropout, dropout inactive in eval)."""
+    B, L, C = x.shape
+    d = sd["embedder.weight"].shape[0]
+    h = F.linear(x.reshape(B, L * C), sd["embedder.weight"], sd["embedder.bias"])  # :420-423
+    h = h + time_embedding(t, sd["time_encoder.W"], sd["time_encoder.dense.weight"],
+                           sd["time_encoder.dense.bias"], d)  # :426 (use_time_axis=False)
+    for i in range(num_layers):
+        p = f"backbone.{i}."
+        u = torch.relu(F.linear(h, sd[p + "0.weight"], sd[p + "0.bias"]))
+        h = h + F.linear(u, sd[p + "3.weight"], sd[p + "3.bias"])  # :429-430
+    out = F.linear(h, sd["unembedder.weight"], sd["unembedder.bias"])  # :433
+    return out.reshape(B, L, C)
+
+
 def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, num_layers: int,
            n_head: int, sde: str, sde_kwargs: Dict[str, float], fourier_noise_scaling: bool,
            num_samples: int, batch_size: int, num_steps: int, noise: Iterable[Tensor],
@@ -581,6 +598,8 @@ def sample(sd: Dict[str, Tensor], *, kind: str, n_channels: int, max_len: int, n
             rec = gate(global_step, max_len, K, R) if use_cache else None
             if kind == "lstm":
                 score = lstm_score_forward(x, t, sd, num_layers)
+            elif kind == "mlp":
+                score = mlp_score_forward(x, t, sd, num_layers)
             else:
                 if use_cache and freqca is not None:  # sampler.py:64-74: cache.update_crf(crf, timestep)
                     score, crf = score_forward(x, t, sd, num_layers, n_head, table, rec, return_crf=True)

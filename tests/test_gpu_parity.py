@@ -530,3 +530,50 @@ def test_freqca_state_golden(ffd, golden, c, chunk):
         assert rel_err(pred.cpu(), g[f"{name}_pred"]) < TOL_HERMITE
     else:
         assert "freq_decomp_count" not in st and cache.predict_crf_freqca(0.5) is None
+
+
+# ------------------------------------------ MLPScoreModule (scope row (f)3) ----
+def make_mlp(c):
+    from fastfourierdiffusion_amd.models.score_models import MLPScoreModule
+    from fastfourierdiffusion_amd.schedulers.sde import VPScheduler
+
+    sch = VPScheduler(fourier_noise_scaling=True, **cases.VP)
+    sch.set_noise_scaling(c["L"])
+    m = MLPScoreModule(n_channels=c["C"], max_len=c["L"], noise_scheduler=sch, d_model=c["d"], d_mlp=c["d_mlp"],
+                       num_layers=c["NL"])
+    sd = to_t(synthetic.mlp_state_dict(c["C"], c["L"], c["d"], c["d_mlp"], c["NL"], seed=c["wseed"]))
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), sch, sd
+
+
+@pytest.mark.parametrize("c", cases.MLP_CASES, ids=lambda c: c["name"])
+def test_mlp_vs_oracle(ffd, c):
+    """Parity UNPINNED against the reference (torchvision.ops.MLP is absent from this image): the HIP path is
+    compared with the oracle restatement of MLPScoreModule.forward (score_models.py:406-440)."""
+    m, sch, sd = make_mlp(c)
+    B, L, C = c["B"], c["L"], c["C"]
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+    for tv in (1.0, 0.37):
+        y = m(batch_of(x.cuda(), tv))
+        assert tuple(y.shape) == (B, L, C)  # tests/test_score_models.py:58-61
+        ref = O.mlp_score_forward(x, torch.full((B,), tv), sd, c["NL"])
+        assert rel_err(y.cpu(), ref) < TOL_SCORE
+    with pytest.raises(AttributeError):
+        m.enable_caching()  # Q9: the reference dereferences backbone.layers, which a ModuleList lacks
+
+
+def test_mlp_trajectory_vs_oracle(ffd):
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    c = cases.MLP_CASES[0]
+    m, sch, sd = make_mlp(c)
+    B, L, C, N = 4, c["L"], c["C"], 12
+    sampler = DiffusionSampler(score_model=m, sample_batch_size=B)
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), 2 * (N + 1), 77))
+    out = sampler.sample(num_samples=2 * B, num_diffusion_steps=N)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), 2 * (N + 1), 77))
+    ts = sch.timesteps
+    ref = O.sample(sd, kind="mlp", n_channels=C, max_len=L, num_layers=c["NL"], n_head=1, sde="vp", sde_kwargs=cases.VP,
+                   fourier_noise_scaling=True, num_samples=2 * B, batch_size=B, num_steps=N, noise=noise)
+    assert tuple(out.shape) == (2 * B, L, C)
+    assert rel_err(out, ref) < TOL_TRAJ
