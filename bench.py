@@ -207,6 +207,24 @@ def main() -> None:
         lib = ctx.lib
         flops_step = lib.ffd_flops_per_sample_step(ctx.handle, 0) * B
         out["achieved_tflops_whole_step"] = flops_step / (ms_per_step * 1e-3) / 1e12
+        # SURVEY 8(d) quotes the metric on a full sampling "incl. prior draw and final idft": time those two
+        # launches (median of 5, device-synchronised) and report the rate with them added to 1000 steps.
+        from fastfourierdiffusion_amd.utils.fourier import idft
+
+        def med_ms(fn):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(device)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            return sorted(ts)[2]
+
+        prior_ms = med_ms(lambda: sampler.sample_prior(B, _sample_offset=offset))
+        idft_ms = med_ms(lambda: idft(X))
+        out["prior_ms"], out["idft_ms"] = prior_ms, idft_ms
+        out["value_incl_prior_idft"] = world * B / (ms_per_step + (prior_ms + idft_ms) / 1000.0)
         if args.workload != "nasa_lstm":
             # dominant kernel, timed in situ: HIP event pairs around every k_ffn_ln launch of 20 more
             # sampling steps on the launch stream (same quantity rocprofv3 --kernel-trace reports)

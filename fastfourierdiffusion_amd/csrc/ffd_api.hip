@@ -30,6 +30,7 @@ struct LstmLayer {
 
 struct LayerPacked {
   float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
+  float *aw_full = nullptr, *aw_q = nullptr;  // per-head packs of the fused in-projection + attention kernel
 };
 
 __global__ void k_add_vec(const float* a, const float* b, float* o, int n) {
@@ -161,8 +162,17 @@ int ffd_tune(const char* key, int value) {
     g_attn_qg = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "dbg")) {
+    g_dbg = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "attn_fused")) {
+    if (value < 0 || value > 1) return FFD_ERR_INVALID;
+    g_attn_fused = value;
+    return FFD_OK;
+  }
   if (!strcmp(key, "attn_impl")) {
-    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    if (value < 0 || value > 3) return FFD_ERR_INVALID;
     g_attn_impl = value;
     return FFD_OK;
   }
@@ -371,6 +381,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if ((rc = dev_alloc(ctx, &pk.in_wp, dpack_floats(3 * d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.q_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.kv_wp, dpack_floats(2 * d, d)))) return rc;
+        if (qkv_attention_supported(d, d / m.n_head)) {
+          if ((rc = dev_alloc(ctx, &pk.aw_full, attn_pack_floats(d, m.n_head, cdiv(3 * (d / m.n_head), 16))))) return rc;
+          if ((rc = dev_alloc(ctx, &pk.aw_q, attn_pack_floats(d, m.n_head, 1)))) return rc;
+        }
         if ((rc = dev_alloc(ctx, &pk.out_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w2p, w2pack_floats(d, F)))) return rc;
@@ -380,6 +394,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(in_w, pk.in_wp, 3 * d, d, s));
       HIPCHECK(launch_pack_dweight(in_w, pk.q_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(in_w + (size_t)d * d, pk.kv_wp, 2 * d, d, s));
+      if (pk.aw_full) {
+        HIPCHECK(launch_pack_attn(in_w, W(pre + "self_attn.in_proj_bias"), pk.aw_full, d, m.n_head, 0, s));
+        HIPCHECK(launch_pack_attn(in_w, W(pre + "self_attn.in_proj_bias"), pk.aw_q, d, m.n_head, 1, s));
+      }
       HIPCHECK(launch_pack_dweight(W(pre + "self_attn.out_proj.weight"), pk.out_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
       HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
@@ -516,6 +534,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
   const int nreg = (mode == PURE) ? 1 : 3;
   const int n_own = (mode == PURE) ? 0 : (mode == MIXED) ? n_rec : L;
   const bool fused = g_fuse_layer == 1 || (g_fuse_layer < 0 && cdiv(M, 64) >= 256);
+  const bool qkv_attn = !fused && g_attn_fused && ctx->packed[0].aw_full != nullptr;
   float* cur = ctx->h0;  // layer input / residual
   float* alt = ctx->h1;
   auto proj_w = [&](int i) { return mode == PURE ? ctx->packed[i].q_wp : ctx->packed[i].in_wp; };
@@ -527,11 +546,19 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
     float* kt = ctx->kt ? ctx->kt + i * lt : nullptr;
     float* vt = ctx->vt ? ctx->vt + i * lt : nullptr;
     const bool tables = (mode == PURE || mode == MIXED);
-    if (!fused) HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
-    HIPCHECK(launch_attention(qreg, kreg, vreg, tables ? kt : nullptr, tables ? vt : nullptr, ctx->attn, B, L, H, hd,
-                              n_own, s));
-    if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
-      HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
+    if (qkv_attn) {
+      // in-projection + attention in one launch: q/k/v never leave the CU (ffd_qkvattn.hip); in MIXED batch
+      // element 0's workgroups also publish their recomputed K/V rows (caching.py:326-328)
+      HIPCHECK(launch_qkv_attention(cur, mode == PURE ? pk.aw_q : pk.aw_full, mode == PURE, tables ? kt : nullptr,
+                                    tables ? vt : nullptr, mode == MIXED ? kt : nullptr, mode == MIXED ? vt : nullptr,
+                                    ctx->attn, B, L, d, hd, n_own, s));
+    } else {
+      if (!fused) HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
+      HIPCHECK(launch_attention(qreg, kreg, vreg, tables ? kt : nullptr, tables ? vt : nullptr, ctx->attn, B, L, H, hd,
+                                n_own, s));
+      if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
+        HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
+    }
     if (fused) {
       NextProj nx{};
       if (i + 1 < m.num_layers) {

@@ -303,7 +303,252 @@ static hipError_t launch_attn_mfma_t(const float* q, const float* k, const float
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// k_attention_pk (attn_impl = 3): same tiling as k_attention_mfma, with the VALU work per (query, key)
+// pair cut from ~11 issue slots to ~6:
+//  * the running-max subtraction rides on the score MFMA: dimension HD of the contraction is
+//    (K side) 1, (Q side) -m_ref[q], so the matrix core returns s - m_ref directly.  m_ref is a *stale*
+//    reference, refreshed only when a tile's maximum exceeds it by more than 2^8 (and on the first tile),
+//    which is exact -- any common factor 2^-m_ref cancels between numerator and denominator;
+//  * P.V and the row sum use packed fp32 (v_pk_fma_f32 / v_pk_add_f32): two output dims per instruction;
+//  * the block maximum uses v_max3_f32.
+// Both lane halves of a query share m_ref, so their partial sums add without a rescale at the end.
+// ---------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int HD, int QG>
+__global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_attention_pk(const float* __restrict__ qg, const float* __restrict__ kg,
+                                                        const float* __restrict__ vg, const float* __restrict__ kt,
+                                                        const float* __restrict__ vt, float* __restrict__ out,
+                                                        int B, int L, int H, int n_own) {
+  constexpr int KST = (HD + 1) / 2;   // k-steps of K^T staged in LDS (real dims)
+  constexpr int KSX = (HD + 2) / 2;   // k-steps issued: dims 0..HD, dim HD carrying the max reference
+  constexpr int SX = HD / 2;          // the k-step that holds dim HD ...
+  constexpr int HX = HD & 1;          // ... in this lane half
+  constexpr int HP = (HD + 1) / 2;    // packed output pairs
+  constexpr float T = 8.0f;
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int pair = blockIdx.x;
+  const int d = H * HD;
+  const int b = pair / H, h = pair - b * H;
+  const int KT = (L + 31) >> 5;
+  const int Lp = KT * 32;
+  float* vs = lds;
+  float* kts = vs + (size_t)Lp * 8;
+  const int half = lane >> 5, l31 = lane & 31;
+
+  // This wave's first query group is requested before the K/V staging so both latencies overlap.
+  const size_t slice = (size_t)pair * L * HD;
+  auto load_q = [&](int qt0, float(&dst)[QG][KSX]) {
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      int q = 32 * (qt0 + g) + l31;
+      if (q >= L) q = L - 1;
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        dst[g][s] = (e < HD) ? qg[slice + (size_t)q * HD + e] : 0.f;
+      }
+    }
+  };
+  float qnext[QG][KSX];
+  load_q(wave * QG < KT ? wave * QG : 0, qnext);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Stage the head once: one thread per key row, all of a row's loads in flight together, zero padding
+  // written in the same pass (rows >= L, V columns >= HD, the odd K^T pad row) -- a single barrier.
+  {
+    const float* kown = kg + slice;
+    const float* vown = vg + slice;
+    const float* ktab = kt ? kt + (size_t)h * L * HD : kown;
+    const float* vtab = vt ? vt + (size_t)h * L * HD : vown;
+#pragma unroll 2
+    for (int j = threadIdx.x; j < Lp; j += blockDim.x) {
+      float kx[2 * KST], vx[8];
+#pragma unroll
+      for (int e = 0; e < 2 * KST; ++e) kx[e] = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vx[e] = 0.f;
+      if (j < L) {
+        const float* kp = (j < n_own ? kown : ktab) + (size_t)j * HD;
+        const float* vp = (j < n_own ? vown : vtab) + (size_t)j * HD;
+        if constexpr (HD % 2 == 0) {  // rows are 8-byte aligned (slice and row sizes are multiples of 2 floats)
+#pragma unroll
+          for (int e = 0; e < HD; e += 2) {
+            const float2 a = *reinterpret_cast<const float2*>(kp + e);
+            const float2 c2 = *reinterpret_cast<const float2*>(vp + e);
+            kx[e] = a.x, kx[e + 1] = a.y, vx[e] = c2.x, vx[e + 1] = c2.y;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < HD; ++e) kx[e] = kp[e], vx[e] = vp[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 2 * KST; ++e) kts[e * Lp + j] = kx[e];
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{vx[0], vx[1], vx[2], vx[3]};
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{vx[4], vx[5], vx[6], vx[7]};
+    }
+  }
+  __syncthreads();
+
+  const float c = 1.4426950408889634f / sqrtf((float)HD);
+  const bool xlane = half == HX;  // lanes whose operand slot in k-step SX is dim HD
+  constexpr int PF = 4;           // V rows in flight
+  auto load_v = [&](int r, int kbase, f32x2(&dst)[4]) {
+    const float* vr = vs + (size_t)(kbase + (r & 3) + 8 * (r >> 2)) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(vr);
+    dst[0] = f32x2{v0.x, v0.y}, dst[1] = f32x2{v0.z, v0.w};
+    if (HD > 4) {
+      const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
+      dst[2] = f32x2{v1.x, v1.y}, dst[3] = f32x2{v1.z, v1.w};
+    } else {
+      dst[2] = f32x2{0.f, 0.f}, dst[3] = f32x2{0.f, 0.f};
+    }
+  };
+  const int QT = KT;
+  for (int qt0 = wave * QG; qt0 < QT; qt0 += nwaves * QG) {
+    float qf[QG][KSX], mref[QG];
+    f32x2 lsum[QG], acc[QG][HP];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) qf[g][s] = qnext[g][s] * c;  // dim HD (the max reference) starts at -m_ref = 0
+      mref[g] = 0.f;
+      lsum[g] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
+    }
+    if (qt0 + nwaves * QG < QT) load_q(qt0 + nwaves * QG, qnext);  // next group's queries under this one's work
+#pragma unroll 1
+    for (int t = 0; t < KT; ++t) {
+      float kf[KSX];
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[(size_t)e * Lp + 32 * t + l31] : 0.f;
+      }
+      if (xlane) kf[SX] = 1.0f;  // the "ones" row that multiplies -m_ref
+      f32x16 sc[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        sc[g] = z;
+      }
+      const int kbase = 32 * t + 4 * half;
+      f32x2 vb[PF][4];
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (32 * t + 32 > L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+#pragma unroll
+          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
+        bm = __builtin_fmaxf(bm, sc[g][15]);
+        const float bmx = fmaxf(bm, __shfl_xor(bm, 32));  // both halves of a query move together
+        if (t == 0 || bmx > T) {  // refresh the reference: new m_ref = old + bmx (tile 0 always has a live key)
+          const float delta = bmx;
+          mref[g] += delta;
+          if (t != 0) {
+            const float corr = __builtin_amdgcn_exp2f(-delta);
+            lsum[g] *= corr;
+#pragma unroll
+            for (int e = 0; e < HP; ++e) acc[g][e] *= corr;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
+          if (xlane) qf[g][SX] = -mref[g];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[g][r]);
+          const float p1 = __builtin_amdgcn_exp2f(sc[g][r + 1]);
+          sc[g][r] = p0;
+          sc[g][r + 1] = p1;
+          lsum[g] += f32x2{p0, p1};
+        }
+      }
+      // P.V with the V rows (LDS broadcast reads) kept PF rows ahead of their use; the first PF rows were
+      // requested before the softmax phase.  sched_barrier pins the requests where they are written.
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        f32x2 vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
+#pragma unroll
+          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
+        }
+        if (r + PF < 16) {
+          load_v(r + PF, kbase, vb[r % PF]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    // ---- add the two lane halves (same query and reference, disjoint keys) and store ----
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      float l = lsum[g].x + lsum[g].y;
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      const int q = 32 * (qt0 + g) + l31;
+      float o[2 * HP];
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        float a0 = acc[g][e].x, a1 = acc[g][e].y;
+        a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 32);
+        o[2 * e] = a0 * inv, o[2 * e + 1] = a1 * inv;
+      }
+      if (half == 0 && q < L && qt0 + g < QT) {
+        float* orow = out + ((size_t)b * L + q) * d + h * HD;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) orow[e] = o[e];
+      }
+    }
+  }
+}
+
+template <int HD, int QG>
+static hipError_t launch_attn_pk_t(const float* q, const float* k, const float* v, const float* kt, const float* vt,
+                                   float* out, int B, int L, int H, int n_own, hipStream_t s) {
+  constexpr int KST = (HD + 1) / 2;
+  const int KT = (L + 31) / 32;
+  const size_t lds = (size_t)KT * 32 * (8 + 2 * KST) * sizeof(float);
+  int nwaves = cdiv(KT, QG);
+  if (nwaves > 4) nwaves = 4;
+  hipLaunchKernelGGL((k_attention_pk<HD, QG>), dim3(B * H), dim3(64 * nwaves), lds, s, q, k, v, kt, vt, out, B, L, H,
+                     n_own);
+  return hipGetLastError();
+}
+
 int g_attn_qg = 0;  // 0 heuristic; 1/2/3 force the q-tile group size (ffd_tune "attn_qg")
+
+template <int HD>
+static hipError_t launch_attn_pk_hd(const float* q, const float* k, const float* v, const float* kt, const float* vt,
+                                    float* out, int B, int L, int H, int n_own, hipStream_t s) {
+  const int QT = (L + 31) / 32;
+  if (g_attn_qg == 1 || QT == 1) return launch_attn_pk_t<HD, 1>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (g_attn_qg == 2) return launch_attn_pk_t<HD, 2>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (g_attn_qg == 3) return launch_attn_pk_t<HD, 3>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  if (QT % 3 == 0) return launch_attn_pk_t<HD, 3>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+  return launch_attn_pk_t<HD, 2>(q, k, v, kt, vt, out, B, L, H, n_own, s);
+}
 
 template <int HD>
 static hipError_t launch_attn_mfma_hd(const float* q, const float* k, const float* v, const float* kt,
@@ -512,6 +757,15 @@ hipError_t launch_attention(const float* qkv, const float* k, const float* v, co
     switch (hd) {
 #define X(h) \
       case h: return launch_attn_v3<h>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
+      FFD_HD_LIST(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (g_attn_impl == 3) {
+    switch (hd) {
+#define X(h) \
+      case h: return launch_attn_pk_hd<h>(qkv, k, v, kt, vt, out, B, L, H, n_own, s);
       FFD_HD_LIST(X)
 #undef X
       default: return hipErrorInvalidValue;

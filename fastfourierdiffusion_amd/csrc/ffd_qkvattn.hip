@@ -1,0 +1,435 @@
+// Fused in-projection + attention: one workgroup per (sample, head).
+//
+// Why: with separate kernels the (B,H,L,hd) q/k/v tensors make a round trip through HBM every layer
+// (83 MB written + 83 MB read at B=512 ECG): the projection kernel's copy-out alone is write-bandwidth
+// bound (21 of its 57 us) and the attention kernel spends ~28 us staging them back.  Here the head's
+// q, k, v rows are produced by the matrix cores straight into the LDS images the attention phase reads
+// (Q^T [dim][token], K^T [dim][token], V [token][8]) and never exist in global memory.
+//
+// Phase 1 (projection, v_mfma_f32_16x16x4_f32): D[token][feature] = x[token][:] . W_h[feature][:] for the
+// head's 3*hd features (q | k | v rows of in_proj, score_models.py:61-66 -> nn.MultiheadAttention), in one or
+// two 16-feature tiles.  x rows go from global memory directly into the A operand -- each lane holds 4
+// consecutive k of its token per 16-wide chunk (float4), the weight pack uses the same k permutation --
+// and the softmax scale log2(e)/sqrt(hd) is folded into the q rows of the pack.
+// Phase 2 (attention): identical to k_attention_pk (ffd_attn.hip): S^T tiles on v_mfma_f32_32x32x2_f32 with the
+// stale-max reference riding on contraction dim hd, packed-fp32 softmax / P.V, V rows pipelined from LDS.
+//
+// E2-CRF cache modes (cached_transformer.py:237-305): `n_own` leading tokens take K/V from the projection,
+// the rest from the shared tables (kt/vt != NULL); PURE (n_own = 0) runs with the q-only weight pack; in
+// MIXED the workgroups of batch element 0 also write their recomputed rows back to the tables
+// (caching.py:326-328).
+#include "ffd_internal.h"
+
+namespace ffd {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- weight pack ---------------------------------------------------------------------------------
+// awp[h][ct][step4][lane][4]: the B operand of k-step (4*step4 + i) for lane (n = lane & 15, q = lane >> 4):
+//   full 16-chunks j < D/16 : k = 16 j + 4 q + i          (step4 = j)
+//   remainder (D % 16) / 4 steps : k = 16 (D/16) + 4 i + q   (step4 = D/16, i < rem steps)
+// feature fi = 16 ct + n -> (reg, e) = (fi / hd, fi % hd) for fi < nf (= 3 hd, or hd for the q-only pack).
+__global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ awp,
+                            float* __restrict__ abp, int D, int H, int hd, int nct, int nf, float qscale) {
+  const int steps4 = (D + 15) / 16;
+  const int total = H * nct * steps4 * 64 * 4;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int i = idx & 3, lane = (idx >> 2) & 63;
+    int rest = idx >> 8;
+    const int j = rest % steps4;
+    rest /= steps4;
+    const int ct = rest % nct, h = rest / nct;
+    const int n = lane & 15, q = lane >> 4;
+    const int fi = 16 * ct + n;
+    int k;
+    if (16 * j + 16 <= D) k = 16 * j + 4 * q + i;
+    else k = (4 * i < D - 16 * j) ? 16 * j + 4 * i + q : -1;
+    float v = 0.f;
+    if (fi < nf && k >= 0 && k < D) {
+      const int reg = fi / hd, e = fi - reg * hd;
+      v = W[(size_t)(reg * D + h * hd + e) * D + k] * (reg == 0 ? qscale : 1.f);
+    }
+    awp[idx] = v;
+  }
+  const int nb = H * nct * 16;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nb; idx += gridDim.x * blockDim.x) {
+    const int n = idx & 15, ct = (idx >> 4) % nct, h = (idx >> 4) / nct;
+    const int fi = 16 * ct + n;
+    float v = 0.f;
+    if (fi < nf) {
+      const int reg = fi / hd, e = fi - reg * hd;
+      v = b[reg * D + h * hd + e] * (reg == 0 ? qscale : 1.f);
+    }
+    abp[idx] = v;
+  }
+}
+
+size_t attn_pack_floats(int D, int H, int nct) { return (size_t)H * nct * ((D + 15) / 16) * 256 + (size_t)H * nct * 16; }
+
+hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int q_only, hipStream_t s) {
+  const int hd = D / H;
+  const int nf = q_only ? hd : 3 * hd;
+  const int nct = cdiv(nf, 16);
+  float* abp = pack + (size_t)H * nct * ((D + 15) / 16) * 256;
+  const float qscale = 1.4426950408889634f / sqrtf((float)hd);
+  hipLaunchKernelGGL(k_pack_attn, dim3(64), dim3(256), 0, s, in_w, in_b, pack, abp, D, H, hd, nct, nf, qscale);
+  return hipGetLastError();
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------
+template <int D, int HD, int QG, int NCT>
+__global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
+    const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
+    const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
+    int B, int L, int n_own, int q_only, int dbg) {
+  constexpr int H = D / HD;
+  constexpr int KST = (HD + 1) / 2;
+  constexpr int KSX = (HD + 2) / 2;
+  constexpr int SX = HD / 2;
+  constexpr int HX = HD & 1;
+  constexpr int HP = (HD + 1) / 2;
+  constexpr int C16 = D / 16;           // full 16-wide k chunks
+  constexpr int REM = (D % 16) / 4;     // remaining k-steps (k = 16*C16 + 4 i + q)
+  constexpr int S4 = (D + 15) / 16;     // float4 groups of packed weight per (h, ct)
+  constexpr float T = 8.0f;
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwaves = blockDim.x >> 6;
+  const int pair = blockIdx.x;
+  const int b = pair / H, h = pair - b * H;
+  const int KT = (L + 31) >> 5;
+  const int Lp = KT * 32;
+  float* vs = lds;                               // V   [Lp][8]
+  float* kts = vs + (size_t)Lp * 8;              // K^T [2*KST][Lp]
+  float* qts = kts + (size_t)2 * KST * Lp;       // Q^T [2*KST][Lp]   (already scaled by log2(e)/sqrt(hd))
+  const int half = lane >> 5, l31 = lane & 31;
+
+  if constexpr (HD % 2 == 1) {  // odd head dims read one pad row / pad column: keep them zero
+    for (int idx = threadIdx.x; idx < Lp * (8 + 4 * KST); idx += blockDim.x) vs[idx] = 0.f;
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ phase 1: projection
+  {
+    const int n = lane & 15, qq = lane >> 4;
+    float4 wf[NCT][S4];
+    const float4* Wq = reinterpret_cast<const float4*>(awp) + (size_t)h * NCT * S4 * 64;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int j = 0; j < S4; ++j) wf[ct][j] = Wq[((size_t)ct * S4 + j) * 64 + lane];
+    const float* abp = awp + (size_t)H * NCT * S4 * 256 + (size_t)h * NCT * 16;
+    float bias[NCT];
+    int kind[NCT], fe[NCT];  // 0 q, 1 k, 2 v, 3 none; feature's index inside its group
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      bias[ct] = abp[ct * 16 + n];
+      const int fi = 16 * ct + n;
+      const int reg = fi / HD;
+      kind[ct] = q_only ? (fi < HD ? 0 : 3) : (reg > 2 ? 3 : reg);
+      fe[ct] = fi - reg * HD;
+    }
+    const float* xb = x + (size_t)b * L * D;
+    const int TT = Lp >> 4;  // every row of the LDS images gets a (finite) value
+    auto load_x = [&](int tt, float4(&xa)[C16 > 0 ? C16 : 1], float(&xr)[REM > 0 ? REM : 1]) {
+      int tok = 16 * tt + n;
+      if (tok >= L) tok = L - 1;  // padded tokens repeat the last row: finite values that are masked / never stored
+      const float* xp = xb + (size_t)tok * D;
+#pragma unroll
+      for (int j = 0; j < C16; ++j) xa[j] = *reinterpret_cast<const float4*>(xp + 16 * j + 4 * qq);
+#pragma unroll
+      for (int i = 0; i < REM; ++i) xr[i] = xp[16 * C16 + 4 * i + qq];
+    };
+    // x tiles are requested PFX tiles ahead: one tile's MFMAs take ~0.5 us, a global load 1-2 us
+    constexpr int PFX = 4;
+    float4 xa[PFX][C16 > 0 ? C16 : 1];
+    float xr[PFX][REM > 0 ? REM : 1];
+#pragma unroll
+    for (int u = 0; u < PFX; ++u)
+      if (wave + u * nwaves < TT) load_x(wave + u * nwaves, xa[u], xr[u]);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int tbase = wave; tbase < TT; tbase += PFX * nwaves) {
+#pragma unroll
+      for (int u = 0; u < PFX; ++u) {
+        const int tt = tbase + u * nwaves;
+        if (tt >= TT) break;
+        f32x4 acc[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < C16; ++j) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].w, wf[ct][j].w, acc[ct]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < REM; ++i) {
+#pragma unroll
+          for (int ct = 0; ct < NCT; ++ct) {
+            const float4 w4 = wf[ct][S4 - 1];
+            const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
+            acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
+          }
+        }
+        if (tt + PFX * nwaves < TT) load_x(tt + PFX * nwaves, xa[u], xr[u]);  // refill this slot
+        __builtin_amdgcn_sched_barrier(0);
+        const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
+                                  acc[ct][3] + bias[ct]};
+          if (kind[ct] == 0) {
+            *reinterpret_cast<float4*>(qts + (size_t)fe[ct] * Lp + t0) = o;
+          } else if (kind[ct] == 1) {
+            *reinterpret_cast<float4*>(kts + (size_t)fe[ct] * Lp + t0) = o;
+          } else if (kind[ct] == 2) {
+            vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
+            vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
+            vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
+            vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
+          }
+        }
+      }
+    }
+  }
+  // rows served by the shared tables (PURE: all of them; MIXED: tokens >= n_own) overwrite / fill K^T and V
+  if (kt != nullptr) {
+    if (!q_only && n_own > 0) __syncthreads();  // MIXED: the projection wrote these rows first
+    const float* ktab = kt + (size_t)h * L * HD;
+    const float* vtab = vt + (size_t)h * L * HD;
+    for (int j = n_own + threadIdx.x; j < L; j += blockDim.x) {
+      float kx[HD], vx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vx[e] = 0.f;
+      const float* kp = ktab + (size_t)j * HD;
+      const float* vp = vtab + (size_t)j * HD;
+      if constexpr (HD % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < HD; e += 2) {
+          const float2 a = *reinterpret_cast<const float2*>(kp + e);
+          const float2 c2 = *reinterpret_cast<const float2*>(vp + e);
+          kx[e] = a.x, kx[e + 1] = a.y, vx[e] = c2.x, vx[e + 1] = c2.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < HD; ++e) kx[e] = kp[e], vx[e] = vp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < HD; ++e) kts[e * Lp + j] = kx[e];
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{vx[0], vx[1], vx[2], vx[3]};
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{vx[4], vx[5], vx[6], vx[7]};
+    }
+    if (q_only) {  // PURE: key rows in [L, Lp) were never written; they are masked but must be finite
+      for (int j = L + threadIdx.x; j < Lp; j += blockDim.x) {
+#pragma unroll
+        for (int e = 0; e < HD; ++e) kts[e * Lp + j] = 0.f;
+        *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  // MIXED: batch element 0 publishes its recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
+  if (kt_out != nullptr && b == 0) {
+    for (int idx = threadIdx.x; idx < n_own * HD; idx += blockDim.x) {
+      const int j = idx / HD, e = idx - j * HD;
+      kt_out[(size_t)h * L * HD + idx] = kts[e * Lp + j];
+      vt_out[(size_t)h * L * HD + idx] = vs[(size_t)j * 8 + e];
+    }
+  }
+
+  // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
+  const bool xlane = half == HX;
+  constexpr int PF = 4;
+  auto load_v = [&](int r, int kbase, f32x2(&dst)[4]) {
+    const float* vr = vs + (size_t)(kbase + (r & 3) + 8 * (r >> 2)) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(vr);
+    dst[0] = f32x2{v0.x, v0.y}, dst[1] = f32x2{v0.z, v0.w};
+    if (HD > 4) {
+      const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
+      dst[2] = f32x2{v1.x, v1.y}, dst[3] = f32x2{v1.z, v1.w};
+    } else {
+      dst[2] = f32x2{0.f, 0.f}, dst[3] = f32x2{0.f, 0.f};
+    }
+  };
+  const int QT = KT;
+  const int d = D;
+  for (int qt0 = wave * QG; qt0 < ((dbg & 1) ? 0 : QT); qt0 += nwaves * QG) {
+    float qf[QG][KSX], mref[QG];
+    f32x2 lsum[QG], acc[QG][HP];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      const int qtile = (qt0 + g < QT) ? qt0 + g : QT - 1;
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;  // dim HD starts at -m_ref = 0
+      }
+      mref[g] = 0.f;
+      lsum[g] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int t = 0; t < KT; ++t) {
+      float kf[KSX];
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[(size_t)e * Lp + 32 * t + l31] : 0.f;
+      }
+      if (xlane) kf[SX] = 1.0f;
+      f32x16 sc[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        sc[g] = z;
+      }
+      const int kbase = 32 * t + 4 * half;
+      f32x2 vb[PF][4];
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (32 * t + 32 > L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+#pragma unroll
+          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
+        bm = __builtin_fmaxf(bm, sc[g][15]);
+        const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
+        if (t == 0 || bmx > T) {
+          const float delta = bmx;
+          mref[g] += delta;
+          if (t != 0) {
+            const float corr = __builtin_amdgcn_exp2f(-delta);
+            lsum[g] *= corr;
+#pragma unroll
+            for (int e = 0; e < HP; ++e) acc[g][e] *= corr;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
+          if (xlane) qf[g][SX] = -mref[g];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[g][r]);
+          const float p1 = __builtin_amdgcn_exp2f(sc[g][r + 1]);
+          sc[g][r] = p0;
+          sc[g][r + 1] = p1;
+          lsum[g] += f32x2{p0, p1};
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        f32x2 vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
+#pragma unroll
+          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
+        }
+        if (r + PF < 16) {
+          load_v(r + PF, kbase, vb[r % PF]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      float l = lsum[g].x + lsum[g].y;
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      const int q = 32 * (qt0 + g) + l31;
+      float o[2 * HP];
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        float a0 = acc[g][e].x, a1 = acc[g][e].y;
+        a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 32);
+        o[2 * e] = a0 * inv, o[2 * e + 1] = a1 * inv;
+      }
+      if (half == 0 && q < L && qt0 + g < QT) {
+        float* orow = out + ((size_t)b * L + q) * d + h * HD;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) orow[e] = o[e];
+      }
+    }
+  }
+}
+
+template <int D, int HD, int QG, int NCT>
+static hipError_t launch_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
+                           float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
+  constexpr int KST = (HD + 1) / 2;
+  const int KT = (L + 31) / 32;
+  const size_t lds = (size_t)KT * 32 * (8 + 4 * KST) * sizeof(float);
+  int nwaves = cdiv(KT, QG);
+  if (nwaves > 4) nwaves = 4;
+  hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x, awp, kt, vt,
+                     kt_out, vt_out, out, B, L, n_own, q_only, g_dbg);
+  return hipGetLastError();
+}
+
+template <int D, int HD>
+static hipError_t launch_dh(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
+                            float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s) {
+  constexpr int NCTF = (3 * HD + 15) / 16;
+  const int QT = (L + 31) / 32;
+  if (q_only) {
+    if (QT == 1) return launch_t<D, HD, 1, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
+    if (QT % 3 == 0) return launch_t<D, HD, 3, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
+    return launch_t<D, HD, 2, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
+  }
+  if (g_attn_qg == 2) return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  if (g_attn_qg == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  if (QT == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  if (QT % 3 == 0) return launch_t<D, HD, 3, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+}
+
+int g_attn_fused = 1;  // 1: fused in-projection + attention where a kernel exists (ffd_tune "attn_fused")
+
+// (d_model, head_dim) pairs with a fused kernel; anything else keeps the two-kernel path.
+bool qkv_attention_supported(int D, int hd) {
+  return (D == 72 && hd == 6) || (D == 60 && hd == 5) || (D == 24 && hd == 6) || (D == 8 && hd == 2) ||
+         (D == 64 && hd == 8) || (D == 48 && hd == 4) || (D == 32 && hd == 8) || (D == 16 && hd == 4) ||
+         (D == 24 && hd == 3);
+}
+
+hipError_t launch_qkv_attention(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
+                                float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd, int n_own,
+                                hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+#define FFD_QA(dd, hh) \
+  if (D == dd && hd == hh) return launch_dh<dd, hh>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+  FFD_QA(72, 6)
+  FFD_QA(60, 5)
+  FFD_QA(24, 6)
+  FFD_QA(8, 2)
+  FFD_QA(64, 8)
+  FFD_QA(48, 4)
+  FFD_QA(32, 8)
+  FFD_QA(16, 4)
+  FFD_QA(24, 3)
+#undef FFD_QA
+  return hipErrorInvalidValue;
+}
+
+}  // namespace ffd

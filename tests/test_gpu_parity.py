@@ -246,23 +246,24 @@ def test_encoders_reference_tests(ffd, golden):
 
 
 # -------------------------------------------------------------- models -----
-@pytest.fixture(params=["auto", "fused", "valu_attn", "mfma4x4_attn"])
+@pytest.fixture(params=["auto", "fused", "unfused", "valu_attn", "mfma4x4_attn", "pk_attn"])
 def variant(request, ffd):
-    """Kernel variants that must all meet the same parity bar: default heuristics, the
-    fused k_layer path forced on (small batches otherwise take the unfused kernels), and
-    the all-VALU attention kernel."""
+    """Kernel variants that must all meet the same parity bar: default heuristics (fused in-projection +
+    attention kernel), the fused k_layer path forced on, the two-kernel projection / attention path
+    ("unfused", hybrid MFMA attention) and its alternative attention kernels."""
     from fastfourierdiffusion_amd import _native as N
 
     lib = N.lib()
     if request.param == "fused":
         assert lib.ffd_tune(b"fuse_layer", 1) == 0
-    elif request.param == "valu_attn":
-        assert lib.ffd_tune(b"attn_impl", 1) == 0
-    elif request.param == "mfma4x4_attn":
-        assert lib.ffd_tune(b"attn_impl", 2) == 0
+    elif request.param != "auto":
+        assert lib.ffd_tune(b"attn_fused", 0) == 0
+        impl = {"unfused": 0, "valu_attn": 1, "mfma4x4_attn": 2, "pk_attn": 3}[request.param]
+        assert lib.ffd_tune(b"attn_impl", impl) == 0
     yield request.param
     lib.ffd_tune(b"fuse_layer", 0)
     lib.ffd_tune(b"attn_impl", 0)
+    lib.ffd_tune(b"attn_fused", 1)
 
 
 @pytest.mark.parametrize("c", cases.MODEL_CASES, ids=lambda c: c["name"])
