@@ -162,10 +162,6 @@ int ffd_tune(const char* key, int value) {
     g_attn_qg = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "dbg")) {
-    g_dbg = value;
-    return FFD_OK;
-  }
   if (!strcmp(key, "attn_fused")) {
     if (value < 0 || value > 1) return FFD_ERR_INVALID;
     g_attn_fused = value;
@@ -382,8 +378,8 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if ((rc = dev_alloc(ctx, &pk.q_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.kv_wp, dpack_floats(2 * d, d)))) return rc;
         if (qkv_attention_supported(d, d / m.n_head)) {
-          if ((rc = dev_alloc(ctx, &pk.aw_full, attn_pack_floats(d, m.n_head, cdiv(3 * (d / m.n_head), 16))))) return rc;
-          if ((rc = dev_alloc(ctx, &pk.aw_q, attn_pack_floats(d, m.n_head, 1)))) return rc;
+          if ((rc = dev_alloc(ctx, &pk.aw_full, attn_pack_floats(d, m.n_head, 1, 0)))) return rc;
+          if ((rc = dev_alloc(ctx, &pk.aw_q, attn_pack_floats(d, m.n_head, 1, 1)))) return rc;
         }
         if ((rc = dev_alloc(ctx, &pk.out_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
@@ -395,8 +391,9 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(in_w, pk.q_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(in_w + (size_t)d * d, pk.kv_wp, 2 * d, d, s));
       if (pk.aw_full) {
-        HIPCHECK(launch_pack_attn(in_w, W(pre + "self_attn.in_proj_bias"), pk.aw_full, d, m.n_head, 0, s));
-        HIPCHECK(launch_pack_attn(in_w, W(pre + "self_attn.in_proj_bias"), pk.aw_q, d, m.n_head, 1, s));
+        const float* in_b = W(pre + "self_attn.in_proj_bias");
+        HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_full, d, m.n_head, 1, 0, s));
+        HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_q, d, m.n_head, 1, 1, s));
       }
       HIPCHECK(launch_pack_dweight(W(pre + "self_attn.out_proj.weight"), pk.out_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));

@@ -118,13 +118,13 @@ extern int g_fuse_layer;
 extern int g_attn_impl;
 extern int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
-size_t attn_pack_floats(int D, int H, int nct);
-hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int q_only, hipStream_t s);
+size_t attn_pack_floats(int D, int H, int hpw, int q_only);
+hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
+                            hipStream_t s);
 bool qkv_attention_supported(int D, int hd);
 hipError_t launch_qkv_attention(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
                                 float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd, int n_own,
                                 hipStream_t s);
-extern int g_dbg;
 extern int g_attn_qg;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]

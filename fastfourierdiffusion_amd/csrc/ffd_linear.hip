@@ -87,7 +87,7 @@ template <int D>
 __global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, const float* __restrict__ Wp,
                                                    const float* __restrict__ bias, float* __restrict__ out0,
                                                    float* __restrict__ out1, float* __restrict__ out2, int M, int N,
-                                                   int L, int H, int hd, unsigned hd_inv, int dbg) {
+                                                   int L, int H, int hd, unsigned hd_inv) {
   constexpr int S = lds_stride(D);
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, 
   for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
-  for (int nt = wave; nt < ((dbg & 1) ? 0 : NT); nt += 4) {
+  for (int nt = wave; nt < NT; nt += 4) {
     if (nt + 4 < NT) {
 #pragma unroll
       for (int g = 0; g < G; ++g) wn[g] = Wq[((size_t)(nt + 4) * G + g) * 64 + lane];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, 
   }
   __syncthreads();
   // copy-out: one (reg*H + h, row) pair per thread iteration = hd contiguous floats
-  const int npairs = (dbg & 2) ? 0 : (N / hd) * R;
+  const int npairs = (N / hd) * R;
   for (int id = threadIdx.x; id < npairs; id += 256) {
     const int rh = id >> 5, row = id & 31;
     const unsigned rb = rowbase[row];
@@ -278,8 +278,6 @@ hipError_t launch_linear(const float* X, const float* Wp, const float* bias, flo
   return hipGetLastError();
 }
 
-int g_dbg = 0;
-
 hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, float* out0, float* out1, float* out2,
                             int M, int nreg, int D, int L, int H, int hd, hipStream_t s) {
   if (M <= 0) return hipSuccess;
@@ -288,7 +286,7 @@ hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, 
   dim3 grid(cdiv(M, 32)), block(256);
   switch (D) {
 #define X(d) \
-    case d: hipLaunchKernelGGL(k_linear_hm<d>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv, g_dbg); break;
+    case d: hipLaunchKernelGGL(k_linear_hm<d>, grid, block, 0, s, X, Wp, bias, out0, out1, out2, M, N, L, H, hd, hd_inv); break;
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -31,15 +31,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   remainder (D % 16) / 4 steps : k = 16 (D/16) + 4 i + q   (step4 = D/16, i < rem steps)
 // feature fi = 16 ct + n -> (reg, e) = (fi / hd, fi % hd) for fi < nf (= 3 hd, or hd for the q-only pack).
 __global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict__ b, float* __restrict__ awp,
-                            float* __restrict__ abp, int D, int H, int hd, int nct, int nf, float qscale) {
+                            float* __restrict__ abp, int D, int H, int hd, int hpw, int nct, int q_only, float qscale) {
+  // one pack per head group (hpw consecutive heads): feature fi -> head hh = fi / fph, then (reg, e)
   const int steps4 = (D + 15) / 16;
-  const int total = H * nct * steps4 * 64 * 4;
+  const int NG = H / hpw;
+  const int fph = q_only ? hd : 3 * hd;  // features per head
+  const int nf = hpw * fph;
+  const int total = NG * nct * steps4 * 64 * 4;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int i = idx & 3, lane = (idx >> 2) & 63;
     int rest = idx >> 8;
     const int j = rest % steps4;
     rest /= steps4;
-    const int ct = rest % nct, h = rest / nct;
+    const int ct = rest % nct, hg = rest / nct;
     const int n = lane & 15, q = lane >> 4;
     const int fi = 16 * ct + n;
     int k;
@@ -47,33 +51,40 @@ __global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict
     else k = (4 * i < D - 16 * j) ? 16 * j + 4 * i + q : -1;
     float v = 0.f;
     if (fi < nf && k >= 0 && k < D) {
-      const int reg = fi / hd, e = fi - reg * hd;
-      v = W[(size_t)(reg * D + h * hd + e) * D + k] * (reg == 0 ? qscale : 1.f);
+      const int hh = fi / fph, f = fi - hh * fph;
+      const int reg = f / hd, e = f - reg * hd;
+      v = W[(size_t)(reg * D + (hg * hpw + hh) * hd + e) * D + k] * (reg == 0 ? qscale : 1.f);
     }
     awp[idx] = v;
   }
-  const int nb = H * nct * 16;
+  const int nb = NG * nct * 16;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < nb; idx += gridDim.x * blockDim.x) {
-    const int n = idx & 15, ct = (idx >> 4) % nct, h = (idx >> 4) / nct;
+    const int n = idx & 15, ct = (idx >> 4) % nct, hg = (idx >> 4) / nct;
     const int fi = 16 * ct + n;
     float v = 0.f;
     if (fi < nf) {
-      const int reg = fi / hd, e = fi - reg * hd;
-      v = b[reg * D + h * hd + e] * (reg == 0 ? qscale : 1.f);
+      const int hh = fi / fph, f = fi - hh * fph;
+      const int reg = f / hd, e = f - reg * hd;
+      v = b[reg * D + (hg * hpw + hh) * hd + e] * (reg == 0 ? qscale : 1.f);
     }
     abp[idx] = v;
   }
 }
 
-size_t attn_pack_floats(int D, int H, int nct) { return (size_t)H * nct * ((D + 15) / 16) * 256 + (size_t)H * nct * 16; }
+static int attn_nct(int hd, int hpw, int q_only) { return cdiv(hpw * (q_only ? hd : 3 * hd), 16); }
 
-hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int q_only, hipStream_t s) {
+size_t attn_pack_floats(int D, int H, int hpw, int q_only) {
+  const int nct = attn_nct(D / H, hpw, q_only);
+  return (size_t)(H / hpw) * nct * ((D + 15) / 16) * 256 + (size_t)(H / hpw) * nct * 16;
+}
+
+hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
+                            hipStream_t s) {
   const int hd = D / H;
-  const int nf = q_only ? hd : 3 * hd;
-  const int nct = cdiv(nf, 16);
-  float* abp = pack + (size_t)H * nct * ((D + 15) / 16) * 256;
+  const int nct = attn_nct(hd, hpw, q_only);
+  float* abp = pack + (size_t)(H / hpw) * nct * ((D + 15) / 16) * 256;
   const float qscale = 1.4426950408889634f / sqrtf((float)hd);
-  hipLaunchKernelGGL(k_pack_attn, dim3(64), dim3(256), 0, s, in_w, in_b, pack, abp, D, H, hd, nct, nf, qscale);
+  hipLaunchKernelGGL(k_pack_attn, dim3(64), dim3(256), 0, s, in_w, in_b, pack, abp, D, H, hd, hpw, nct, q_only, qscale);
   return hipGetLastError();
 }
 
@@ -82,7 +93,7 @@ template <int D, int HD, int QG, int NCT>
 __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
-    int B, int L, int n_own, int q_only, int dbg) {
+    int B, int L, int n_own, int q_only) {
   constexpr int H = D / HD;
   constexpr int KST = (HD + 1) / 2;
   constexpr int KSX = (HD + 2) / 2;
@@ -96,8 +107,21 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
-  const int pair = blockIdx.x;
-  const int b = pair / H, h = pair - b * H;
+  // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.
+  // All H heads of a sample read the same x rows, so they are placed on one XCD: x is fetched into one L2
+  // once instead of into (up to) eight.
+  int b, h;
+  {
+    const int pair = blockIdx.x;
+    const int nmain = (B >> 3) * 8 * H;
+    if (pair < nmain) {
+      const int xcd = pair & 7, slot = pair >> 3;
+      const int sb = slot / H;
+      b = sb * 8 + xcd, h = slot - sb * H;
+    } else {
+      b = pair / H, h = pair - b * H;
+    }
+  }
   const int KT = (L + 31) >> 5;
   const int Lp = KT * 32;
   float* vs = lds;                               // V   [Lp][8]
@@ -146,53 +170,56 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     float4 xa[PFX][C16 > 0 ? C16 : 1];
     float xr[PFX][REM > 0 ? REM : 1];
 #pragma unroll
-    for (int u = 0; u < PFX; ++u)
-      if (wave + u * nwaves < TT) load_x(wave + u * nwaves, xa[u], xr[u]);
+    for (int u = 0; u < PFX; ++u)  // unconditional (tile index clamped): conditional loads would force vmcnt(0) waits
+      load_x(min(wave + u * nwaves, TT - 1), xa[u], xr[u]);
     __builtin_amdgcn_sched_barrier(0);
-    for (int tbase = wave; tbase < TT; tbase += PFX * nwaves) {
+    // Straight-line code (full unroll, forward exits only): a loop back-edge would make the compiler wait for
+    // *all* outstanding loads at every tile (vmcnt(0)), which defeats the ring.  MAXT tiles per wave cover
+    // L <= 512 with 4 waves.
+    constexpr int MAXT = 8;
 #pragma unroll
-      for (int u = 0; u < PFX; ++u) {
-        const int tt = tbase + u * nwaves;
-        if (tt >= TT) break;
-        f32x4 acc[NCT];
+    for (int it = 0; it < MAXT; ++it) {
+      const int u = it % PFX;
+      const int tt = wave + it * nwaves;
+      if (tt >= TT) break;
+      f32x4 acc[NCT];
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < C16; ++j) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
-            acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
-            acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
-            acc[ct] = mfma16(xa[u][j].w, wf[ct][j].w, acc[ct]);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < REM; ++i) {
-#pragma unroll
-          for (int ct = 0; ct < NCT; ++ct) {
-            const float4 w4 = wf[ct][S4 - 1];
-            const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
-            acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
-          }
-        }
-        if (tt + PFX * nwaves < TT) load_x(tt + PFX * nwaves, xa[u], xr[u]);  // refill this slot
-        __builtin_amdgcn_sched_barrier(0);
-        const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
+      for (int j = 0; j < C16; ++j) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-          const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
-                                  acc[ct][3] + bias[ct]};
-          if (kind[ct] == 0) {
-            *reinterpret_cast<float4*>(qts + (size_t)fe[ct] * Lp + t0) = o;
-          } else if (kind[ct] == 1) {
-            *reinterpret_cast<float4*>(kts + (size_t)fe[ct] * Lp + t0) = o;
-          } else if (kind[ct] == 2) {
-            vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
-            vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
-            vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
-            vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
-          }
+          acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
+          acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
+          acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
+          acc[ct] = mfma16(xa[u][j].w, wf[ct][j].w, acc[ct]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < REM; ++i) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float4 w4 = wf[ct][S4 - 1];
+          const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
+          acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
+        }
+      }
+      if (it + PFX < MAXT) load_x(min(tt + PFX * nwaves, TT - 1), xa[u], xr[u]);  // refill this slot (clamped, unconditional)
+      __builtin_amdgcn_sched_barrier(0);
+      const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
+                                acc[ct][3] + bias[ct]};
+        if (kind[ct] == 0) {
+          *reinterpret_cast<float4*>(qts + (size_t)fe[ct] * Lp + t0) = o;
+        } else if (kind[ct] == 1) {
+          *reinterpret_cast<float4*>(kts + (size_t)fe[ct] * Lp + t0) = o;
+        } else if (kind[ct] == 2) {
+          vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
+          vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
+          vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
+          vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
         }
       }
     }
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   };
   const int QT = KT;
   const int d = D;
-  for (int qt0 = wave * QG; qt0 < ((dbg & 1) ? 0 : QT); qt0 += nwaves * QG) {
+  for (int qt0 = wave * QG; qt0 < QT; qt0 += nwaves * QG) {
     float qf[QG][KSX], mref[QG];
     f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
@@ -383,7 +410,7 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
   int nwaves = cdiv(KT, QG);
   if (nwaves > 4) nwaves = 4;
   hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x, awp, kt, vt,
-                     kt_out, vt_out, out, B, L, n_own, q_only, g_dbg);
+                     kt_out, vt_out, out, B, L, n_own, q_only);
   return hipGetLastError();
 }
 
