@@ -266,7 +266,7 @@ def main() -> None:
                 model.disable_caching()
                 out["cache_ratio"] = {"off_over_on": t_off / t_on, "ms_off": t_off * 1e3, "ms_on": t_on * 1e3,
                                       "batch": B, "note": "pure-cache steps (K/V projections skipped), 200 steps"}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (a bounded ~25 s CPU sample)
             out["cpu_baseline"] = cpu_baseline(sd, L, Cn, model.num_layers, model.n_head,
                                                "lstm" if args.workload == "nasa_lstm" else "transformer")
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
