@@ -38,8 +38,12 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // current chunk runs (their latency is hidden behind CH recurrence steps), parked in LDS at the
 // chunk boundary, and the inner loop works on LDS only (a per-step global load would put a full
 // s_waitcnt vmcnt(0) memory round trip on the critical path of every cell step).
+// A 5-wave workgroup (d = 72: 288 threads) puts two of its waves on SIMD 0; at 3 waves per SIMD a second workgroup
+// then never fits next to it and the CU runs one sequence at a time (measured: time exactly doubled from B=256 to
+// B=512).  Capping the VGPRs at 128 (4 waves per SIMD; the spills land on the chunk boundaries, not in the cell
+// step) lets two workgroups share a CU: 3.75 -> 2.64 ms per diffusion step at B=512.
 template <int D, int BT>
-__global__ __launch_bounds__(320) void k_lstm_layer(float* __restrict__ x, const float* __restrict__ gx,
+__global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) void k_lstm_layer(float* __restrict__ x, const float* __restrict__ gx,
                                                     const float* __restrict__ whh, int B, int L) {
   constexpr int G4 = 4 * D;
   constexpr int CH = 16;
