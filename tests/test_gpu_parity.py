@@ -310,6 +310,25 @@ def test_model_vs_oracle_ragged_batches(ffd):
         assert rel_err(out.cpu(), ref) < TOL_SCORE, B
 
 
+def test_cached_modes_vs_oracle_batch_across_xcds(ffd, variant):
+    """FULL -> PURE -> MIXED -> PURE -> STD-like (n > 0.8 L) with B=19: the fused kernel places samples 0..15 by
+    its XCD-aware block remap and 16..18 directly; every sample must see batch element 0's tables (Q1)."""
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "reftest")
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    B, L, C = 19, c["L"], c["C"]
+    m.enable_caching()
+    m.cache.reset()
+    table = O.KVTable(c["NL"], L)
+    for j, n in enumerate([L, 0, 10, 0, L - 3]):
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 7000 + j)))
+        t = torch.full((B,), 0.55, dtype=torch.float32)
+        ref = O.score_forward(x, t, sd, c["NL"], c["H"], table, list(range(n)))
+        out = m(batch_of(x.cuda(), 0.55), recompute_tokens=set(range(n)), step=j)
+        assert rel_err(out.cpu(), ref) < TOL_SCORE, (j, n)
+    m.disable_caching()
+
+
 def test_model_full_batch_properties(ffd):
     """BASELINE configs[1] batch (B=512): sample independence (a size-independent
     property of the path) -- every sample of a big batch equals its own B=1 evaluation
