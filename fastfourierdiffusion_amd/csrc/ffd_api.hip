@@ -30,7 +30,8 @@ struct LstmLayer {
 
 struct LayerPacked {
   float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
-  float *aw_full = nullptr, *aw_q = nullptr;  // per-head packs of the fused in-projection + attention kernel
+  float *aw_full = nullptr, *aw_q = nullptr;    // per-head packs of the fused in-projection + attention kernel
+  float *aw_full2 = nullptr, *aw_q2 = nullptr;  // same, per pair of heads (two-head workgroups)
 };
 
 __global__ void k_add_vec(const float* a, const float* b, float* o, int n) {
@@ -160,6 +161,11 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "attn_qg")) {
     if (value < 0 || value > 3) return FFD_ERR_INVALID;
     g_attn_qg = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "attn_hpw")) {
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_attn_hpw = value;
     return FFD_OK;
   }
   if (!strcmp(key, "attn_fused")) {
@@ -380,6 +386,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if (qkv_attention_supported(d, d / m.n_head)) {
           if ((rc = dev_alloc(ctx, &pk.aw_full, attn_pack_floats(d, m.n_head, 1, 0)))) return rc;
           if ((rc = dev_alloc(ctx, &pk.aw_q, attn_pack_floats(d, m.n_head, 1, 1)))) return rc;
+          if (m.n_head % 2 == 0) {
+            if ((rc = dev_alloc(ctx, &pk.aw_full2, attn_pack_floats(d, m.n_head, 2, 0)))) return rc;
+            if ((rc = dev_alloc(ctx, &pk.aw_q2, attn_pack_floats(d, m.n_head, 2, 1)))) return rc;
+          }
         }
         if ((rc = dev_alloc(ctx, &pk.out_wp, dpack_floats(d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
@@ -394,6 +404,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         const float* in_b = W(pre + "self_attn.in_proj_bias");
         HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_full, d, m.n_head, 1, 0, s));
         HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_q, d, m.n_head, 1, 1, s));
+        if (pk.aw_full2) {
+          HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_full2, d, m.n_head, 2, 0, s));
+          HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_q2, d, m.n_head, 2, 1, s));
+        }
       }
       HIPCHECK(launch_pack_dweight(W(pre + "self_attn.out_proj.weight"), pk.out_wp, d, d, s));
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
@@ -546,7 +560,9 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
     if (qkv_attn) {
       // in-projection + attention in one launch: q/k/v never leave the CU (ffd_qkvattn.hip); in MIXED batch
       // element 0's workgroups also publish their recomputed K/V rows (caching.py:326-328)
-      HIPCHECK(launch_qkv_attention(cur, mode == PURE ? pk.aw_q : pk.aw_full, mode == PURE, tables ? kt : nullptr,
+      const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L) : 1;
+      const float* pack = hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
+      HIPCHECK(launch_qkv_attention(cur, pack, hpw, mode == PURE, tables ? kt : nullptr,
                                     tables ? vt : nullptr, mode == MIXED ? kt : nullptr, mode == MIXED ? vt : nullptr,
                                     ctx->attn, B, L, d, hd, n_own, s));
     } else {

@@ -122,9 +122,11 @@ size_t attn_pack_floats(int D, int H, int hpw, int q_only);
 hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
                             hipStream_t s);
 bool qkv_attention_supported(int D, int hd);
-hipError_t launch_qkv_attention(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
-                                float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd, int n_own,
-                                hipStream_t s);
+int qkv_attention_hpw(int D, int hd, int L);
+extern int g_attn_hpw;
+hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
+                                const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
+                                int n_own, hipStream_t s);
 extern int g_attn_qg;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]

@@ -401,6 +401,355 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   }
 }
 
+// ---- multi-head variant ------------------------------------------------------------------------------
+// HPW heads of one sample per workgroup (2 waves per head).  Why: with one head per workgroup every
+// workgroup re-reads the sample's x rows and its own weight slice, and the kernel is paced by the L1 request
+// rate at workgroup start (measured: ~20k cycles until a wave's second tile vs ~2.3k per tile afterwards).
+// Here x is read once for HPW heads, the HPW*3*hd features are packed densely into 16-wide tiles
+// (2 heads x 18 = 36 features -> 3 tiles, 75 % useful, vs 18 -> 2 tiles, 56 %), and the weight pack is
+// staged once in LDS and read as the MFMA B operand from there.  Two heads = 4 waves, one per SIMD: a 6-wave
+// workgroup (3 heads) leaves the CU with a single resident workgroup (two of its waves land on SIMDs 0 and 1,
+// so a second one never fits at 3 waves per SIMD) and was slower.
+template <int D, int HD, int HPW, int QG, int NCT>
+__global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
+    const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
+    const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
+    int B, int L, int n_own, int q_only) {
+  constexpr int H = D / HD;
+  constexpr int NG = H / HPW;
+  constexpr int KST = (HD + 1) / 2;
+  constexpr int KSX = (HD + 2) / 2;
+  constexpr int SX = HD / 2;
+  constexpr int HX = HD & 1;
+  constexpr int HP = (HD + 1) / 2;
+  constexpr int C16 = D / 16;
+  constexpr int REM = (D % 16) / 4;
+  constexpr int S4 = (D + 15) / 16;
+  constexpr int NW = 2 * HPW;           // waves per workgroup
+  constexpr int MAXT = 3;               // token tiles per wave: Lp <= 192 -> 12 tiles over >= 4 waves
+  constexpr float T = 8.0f;
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int b, hg;
+  {
+    const int pair = blockIdx.x;
+    const int nmain = (B >> 3) * 8 * NG;
+    if (pair < nmain) {  // all head groups of a sample on one XCD (see k_qkv_attention)
+      const int xcd = pair & 7, slot = pair >> 3;
+      const int sb = slot / NG;
+      b = sb * 8 + xcd, hg = slot - sb * NG;
+    } else {
+      b = pair / NG, hg = pair - b * NG;
+    }
+  }
+  const int KT = (L + 31) >> 5;
+  const int Lp = KT * 32;
+  const int RS = Lp * (8 + 4 * KST);                           // floats per head region: V | K^T | Q^T
+  float4* wl = reinterpret_cast<float4*>(lds + (size_t)HPW * RS);  // weight pack [NCT][S4][64] float4
+  const int half = lane >> 5, l31 = lane & 31;
+  const int fph = q_only ? HD : 3 * HD;                        // features per head in this pack
+
+  // ------------------------------------------------------------------ phase 1: projection
+  {
+    const int n = lane & 15, qq = lane >> 4;
+    const float* xb = x + (size_t)b * L * D;
+    const int TT = Lp >> 4;
+    auto load_x = [&](int tt, float4(&xa)[C16 > 0 ? C16 : 1], float(&xr)[REM > 0 ? REM : 1]) {
+      int tok = 16 * tt + n;
+      if (tok >= L) tok = L - 1;
+      const float* xp = xb + (size_t)tok * D;
+#pragma unroll
+      for (int j = 0; j < C16; ++j) xa[j] = *reinterpret_cast<const float4*>(xp + 16 * j + 4 * qq);
+#pragma unroll
+      for (int i = 0; i < REM; ++i) xr[i] = xp[16 * C16 + 4 * i + qq];
+    };
+    // every x tile of this wave is requested up front (unconditional, clamped), then the weights are staged
+    float4 xa[MAXT][C16 > 0 ? C16 : 1];
+    float xr[MAXT][REM > 0 ? REM : 1];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) load_x(min(wave + u * NW, TT - 1), xa[u], xr[u]);
+    {
+      const float4* Wq = reinterpret_cast<const float4*>(awp) + (size_t)hg * NCT * S4 * 64;
+      for (int i = threadIdx.x; i < NCT * S4 * 64; i += 64 * NW) wl[i] = Wq[i];
+      if constexpr (HD % 2 == 1) {  // odd head dims read one pad row / pad column: keep them zero
+        for (int idx = threadIdx.x; idx < HPW * RS; idx += 64 * NW) lds[idx] = 0.f;
+      }
+    }
+    const float* abp = awp + (size_t)NG * NCT * S4 * 256 + (size_t)hg * NCT * 16;
+    float bias[NCT];
+    int kind[NCT], fe[NCT], fh[NCT];  // 0 q, 1 k, 2 v, 3 none; index inside its group; head inside the workgroup
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      bias[ct] = abp[ct * 16 + n];
+      const int fi = 16 * ct + n;
+      const int hh = fi / fph, f = fi - hh * fph;
+      const int reg = f / HD;
+      fh[ct] = hh < HPW ? hh : 0;
+      kind[ct] = hh >= HPW ? 3 : reg;
+      fe[ct] = f - reg * HD;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAXT; ++it) {
+      const int tt = wave + it * NW;
+      if (tt >= TT) break;
+      f32x4 acc[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < C16; ++j) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float4 w4 = wl[(ct * S4 + j) * 64 + lane];
+          acc[ct] = mfma16(xa[it][j].x, w4.x, acc[ct]);
+          acc[ct] = mfma16(xa[it][j].y, w4.y, acc[ct]);
+          acc[ct] = mfma16(xa[it][j].z, w4.z, acc[ct]);
+          acc[ct] = mfma16(xa[it][j].w, w4.w, acc[ct]);
+        }
+      }
+      if constexpr (REM > 0) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const float4 w4 = wl[(ct * S4 + S4 - 1) * 64 + lane];
+#pragma unroll
+          for (int i = 0; i < REM; ++i) {
+            const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
+            acc[ct] = mfma16(xr[it][i], wv, acc[ct]);
+          }
+        }
+      }
+      const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        float* reg_vs = lds + (size_t)fh[ct] * RS;
+        float* reg_kts = reg_vs + (size_t)Lp * 8;
+        float* reg_qts = reg_kts + (size_t)2 * KST * Lp;
+        const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
+                                acc[ct][3] + bias[ct]};
+        if (kind[ct] == 0) {
+          *reinterpret_cast<float4*>(reg_qts + (size_t)fe[ct] * Lp + t0) = o;
+        } else if (kind[ct] == 1) {
+          *reinterpret_cast<float4*>(reg_kts + (size_t)fe[ct] * Lp + t0) = o;
+        } else if (kind[ct] == 2) {
+          reg_vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
+          reg_vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
+          reg_vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
+          reg_vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
+        }
+      }
+    }
+  }
+  // this wave's head for the rest of the kernel
+  const int hh = wave >> 1, gw = wave & 1;
+  const int h = hg * HPW + hh;
+  float* vs = lds + (size_t)hh * RS;
+  float* kts = vs + (size_t)Lp * 8;
+  float* qts = kts + (size_t)2 * KST * Lp;
+  // rows served by the shared tables (PURE: all of them; MIXED: tokens >= n_own): the head's two waves fill them
+  if (kt != nullptr) {
+    if (!q_only && n_own > 0) __syncthreads();  // MIXED: the projection wrote these rows first
+    const float* ktab = kt + (size_t)h * L * HD;
+    const float* vtab = vt + (size_t)h * L * HD;
+    const int tid2 = gw * 64 + lane;  // 0..127 inside the head's wave pair
+    for (int j = n_own + tid2; j < L; j += 128) {
+      float kx[HD], vx[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vx[e] = 0.f;
+      const float* kp = ktab + (size_t)j * HD;
+      const float* vp = vtab + (size_t)j * HD;
+      if constexpr (HD % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < HD; e += 2) {
+          const float2 a = *reinterpret_cast<const float2*>(kp + e);
+          const float2 c2 = *reinterpret_cast<const float2*>(vp + e);
+          kx[e] = a.x, kx[e + 1] = a.y, vx[e] = c2.x, vx[e + 1] = c2.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < HD; ++e) kx[e] = kp[e], vx[e] = vp[e];
+      }
+#pragma unroll
+      for (int e = 0; e < HD; ++e) kts[e * Lp + j] = kx[e];
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{vx[0], vx[1], vx[2], vx[3]};
+      *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{vx[4], vx[5], vx[6], vx[7]};
+    }
+    if (q_only) {  // PURE: key rows in [L, Lp) were never written; they are masked but must be finite
+      for (int j = L + tid2; j < Lp; j += 128) {
+#pragma unroll
+        for (int e = 0; e < HD; ++e) kts[e * Lp + j] = 0.f;
+        *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  __syncthreads();
+  if (kt_out != nullptr && b == 0) {  // MIXED: batch element 0 publishes its recomputed rows
+    const int tid2 = gw * 64 + lane;
+    for (int idx = tid2; idx < n_own * HD; idx += 128) {
+      const int j = idx / HD, e = idx - j * HD;
+      kt_out[(size_t)h * L * HD + idx] = kts[e * Lp + j];
+      vt_out[(size_t)h * L * HD + idx] = vs[(size_t)j * 8 + e];
+    }
+  }
+
+  // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
+  const bool xlane = half == HX;
+  constexpr int PF = 4;
+  auto load_v = [&](int r, int kbase, f32x2(&dst)[4]) {
+    const float* vr = vs + (size_t)(kbase + (r & 3) + 8 * (r >> 2)) * 8;
+    const float4 v0 = *reinterpret_cast<const float4*>(vr);
+    dst[0] = f32x2{v0.x, v0.y}, dst[1] = f32x2{v0.z, v0.w};
+    if (HD > 4) {
+      const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
+      dst[2] = f32x2{v1.x, v1.y}, dst[3] = f32x2{v1.z, v1.w};
+    } else {
+      dst[2] = f32x2{0.f, 0.f}, dst[3] = f32x2{0.f, 0.f};
+    }
+  };
+  const int QT = KT;
+  for (int qt0 = gw * QG; qt0 < QT; qt0 += 2 * QG) {
+    float qf[QG][KSX], mref[QG];
+    f32x2 lsum[QG], acc[QG][HP];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      const int qtile = (qt0 + g < QT) ? qt0 + g : QT - 1;
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;
+      }
+      mref[g] = 0.f;
+      lsum[g] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int t = 0; t < KT; ++t) {
+      float kf[KSX];
+#pragma unroll
+      for (int s = 0; s < KSX; ++s) {
+        const int e = 2 * s + half;
+        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[(size_t)e * Lp + 32 * t + l31] : 0.f;
+      }
+      if (xlane) kf[SX] = 1.0f;
+      f32x16 sc[QG];
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KSX; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        sc[g] = z;
+      }
+      const int kbase = 32 * t + 4 * half;
+      f32x2 vb[PF][4];
+#pragma unroll
+      for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (32 * t + 32 > L) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+#pragma unroll
+          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < QG; ++g) {
+        float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
+        bm = __builtin_fmaxf(bm, sc[g][15]);
+        const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
+        if (t == 0 || bmx > T) {
+          const float delta = bmx;
+          mref[g] += delta;
+          if (t != 0) {
+            const float corr = __builtin_amdgcn_exp2f(-delta);
+            lsum[g] *= corr;
+#pragma unroll
+            for (int e = 0; e < HP; ++e) acc[g][e] *= corr;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
+          if (xlane) qf[g][SX] = -mref[g];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[g][r]);
+          const float p1 = __builtin_amdgcn_exp2f(sc[g][r + 1]);
+          sc[g][r] = p0;
+          sc[g][r + 1] = p1;
+          lsum[g] += f32x2{p0, p1};
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        f32x2 vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
+#pragma unroll
+        for (int g = 0; g < QG; ++g) {
+          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
+#pragma unroll
+          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
+        }
+        if (r + PF < 16) {
+          load_v(r + PF, kbase, vb[r % PF]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < QG; ++g) {
+      float l = lsum[g].x + lsum[g].y;
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      const int q = 32 * (qt0 + g) + l31;
+      float o[2 * HP];
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        float a0 = acc[g][e].x, a1 = acc[g][e].y;
+        a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 32);
+        o[2 * e] = a0 * inv, o[2 * e + 1] = a1 * inv;
+      }
+      if (half == 0 && q < L && qt0 + g < QT) {
+        float* orow = out + ((size_t)b * L + q) * D + h * HD;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) orow[e] = o[e];
+      }
+    }
+  }
+}
+
+template <int D, int HD, int HPW, int QG, int NCT>
+static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
+                              float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
+  constexpr int KST = (HD + 1) / 2;
+  constexpr int S4 = (D + 15) / 16;
+  const int KT = (L + 31) / 32;
+  const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256) * sizeof(float);
+  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
+  hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
+                     n_own, q_only);
+  return hipGetLastError();
+}
+
+// 2 heads per workgroup, 2 waves per head: L <= 192 (<= 3 q-tiles per wave, 12 token tiles over 4 waves)
+template <int D, int HD>
+static hipError_t launch_mh2(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
+                             float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s) {
+  constexpr int NF = (2 * 3 * HD + 15) / 16, NQ = (2 * HD + 15) / 16;
+  const int QG = cdiv((L + 31) / 32, 2);
+#define FFD_MH(qg)                                                                                                   \
+  if (QG == qg)                                                                                                      \
+    return q_only ? launch_mh_t<D, HD, 2, qg, NQ>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s)            \
+                  : launch_mh_t<D, HD, 2, qg, NF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  FFD_MH(1) FFD_MH(2) FFD_MH(3)
+#undef FFD_MH
+  return hipErrorInvalidValue;
+}
+
 template <int D, int HD, int QG, int NCT>
 static hipError_t launch_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
                            float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
@@ -440,10 +789,24 @@ bool qkv_attention_supported(int D, int hd) {
          (D == 24 && hd == 3);
 }
 
-hipError_t launch_qkv_attention(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
-                                float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd, int n_own,
-                                hipStream_t s) {
+int g_attn_hpw = 0;  // 0 heuristic, 1 / 2 force heads per workgroup (ffd_tune "attn_hpw")
+
+// heads per workgroup the fused kernel uses for this shape (the caller passes the matching weight pack)
+int qkv_attention_hpw(int D, int hd, int L) {
+  const bool mh2 = ((D == 72 && hd == 6) || (D == 60 && hd == 5) || (D == 48 && hd == 4)) && L <= 192;
+  return (g_attn_hpw == 1 || !mh2) ? 1 : 2;
+}
+
+hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
+                                const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
+                                int n_own, hipStream_t s) {
   if (B <= 0) return hipSuccess;
+  if (hpw == 2) {
+    if (D == 72 && hd == 6) return launch_mh2<72, 6>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+    if (D == 60 && hd == 5) return launch_mh2<60, 5>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+    if (D == 48 && hd == 4) return launch_mh2<48, 4>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+    return hipErrorInvalidValue;
+  }
 #define FFD_QA(dd, hh) \
   if (D == dd && hd == hh) return launch_dh<dd, hh>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
   FFD_QA(72, 6)
