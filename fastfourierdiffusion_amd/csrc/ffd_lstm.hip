@@ -4,8 +4,8 @@
 // The input projection gx = x W_ih^T + (b_ih + b_hh) for all L positions is one
 // MFMA GEMM (k_linear); this kernel runs the L-step recurrence.  The recurrence is
 // latency-bound (L sequential cell steps), so a workgroup owns BT samples for the
-// whole sequence: thread j keeps row j of W_hh (d floats) in VGPRs for all L steps,
-// h lives in LDS and is broadcast-read, c lives in the registers of the cell threads.
+// whole sequence: W_hh lives in VGPRs for all L steps (see the thread layout below),
+// h lives in LDS, c in the registers of the cell threads.
 #include "ffd_internal.h"
 
 namespace ffd {
@@ -22,10 +22,20 @@ __device__ __forceinline__ float tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
-// Thread layout: tid = 4*e + gate -- the four gates (i, f, g, o) of hidden unit e sit in one lane quad,
-// so after the dot products the activated gate values are exchanged with four DPP quad-broadcasts
-// (no LDS round trip), every lane of the quad updates c/h redundantly, and one barrier per cell step
-// (h is double-buffered in LDS) is all the synchronisation the recurrence needs.
+// Thread layout: tid = 4*e + j -- the lane quad of hidden unit e splits the recurrent dot products over k:
+// lane j holds W_hh[gate][e][k-slice j] for all four gates (i, f, g, o) of its unit (4 x D/4 weights in VGPRs) and
+// reads only its quarter of h from LDS, so the h broadcast costs a quarter of the LDS bandwidth it would with one
+// full row per lane (that broadcast paced the cell step once two workgroups shared a CU).  The four partial sums
+// per gate are added across the quad with two DPP xor-adds, lane j then activates gate j, the activated gates are
+// exchanged with four DPP quad-broadcasts (no LDS round trip), every lane of the quad updates c/h redundantly,
+// and one barrier per cell step (h is double-buffered in LDS) is all the synchronisation the recurrence needs.
+template <int P>
+__device__ __forceinline__ float quad_xor_add(float v) {
+  // v + (value of the lane whose index inside the quad differs by xor P), P = 1 or 2
+  constexpr int perm = (P == 1) ? (1 | (0 << 2) | (3 << 4) | (2 << 6)) : (2 | (3 << 2) | (0 << 4) | (1 << 6));
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), perm, 0xF, 0xF, true));
+}
+
 template <int K>
 __device__ __forceinline__ float quad_bcast(float v) {
   // quad_perm:[K,K,K,K] : every lane of a quad reads lane K of that quad
@@ -51,23 +61,29 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
   constexpr int XQ = CH * D / 4;   // float4 per sample per chunk (residual rows)
   constexpr int NT = ((G4 + 63) / 64) * 64;
   constexpr int GPT = (GQ + NT - 1) / NT, XPT = (XQ + NT - 1) / NT;
-  __shared__ __align__(16) float hbuf[2][BT][D];
+  constexpr int KQ = ((D / 4 + 3) / 4) * 4;  // k-slice length per lane of the quad, padded to whole float4 (zeros)
+  __shared__ __align__(16) float hbuf[2][BT][4 * KQ];  // h, slice-major: unit k lives at (k / (D/4)) * KQ + k % (D/4)
   __shared__ __align__(16) float gxs[BT][CH * G4];
   __shared__ __align__(16) float xsb[BT][CH * D];
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * BT;
   const bool live = tid < G4;
-  const int e = live ? tid >> 2 : 0, gate = tid & 3;
-  const int rowi = gate * D + e;  // row of W_hh / column of the gate pre-activations
+  static_assert(D % 4 == 0, "the quad splits k into four equal slices");
+  constexpr int DQ = D / 4;
+  const int e = live ? tid >> 2 : 0, gate = tid & 3;  // `gate` doubles as this lane's k-slice index j
+  const int rowi = gate * D + e;  // column of the gate pre-activations this lane activates
   const bool writer = live && gate == 0;
+  const int hpos = (e / DQ) * KQ + (e % DQ);  // where unit e sits in the slice-major h buffer
 
-  float w[D];
+  float w[4][KQ];  // W_hh[g*D + e][gate*DQ + k], zero padded
 #pragma unroll
-  for (int k = 0; k < D; ++k) w[k] = whh[(size_t)rowi * D + k];
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) w[g][k] = (k < DQ) ? whh[(size_t)(g * D + e) * D + gate * DQ + k] : 0.f;
   float c[BT];
 #pragma unroll
   for (int bt = 0; bt < BT; ++bt) c[bt] = 0.f;
-  for (int i = tid; i < 2 * BT * D; i += blockDim.x) (&hbuf[0][0][0])[i] = 0.f;
+  for (int i = tid; i < 2 * BT * 4 * KQ; i += blockDim.x) (&hbuf[0][0][0])[i] = 0.f;
 
   // activation constants: gate 2 (g) is tanh, the others sigmoid; both are rcp(1 + exp2(s*x)) based
   const float sarg = (gate == 2) ? 2.8853900817779268f : -1.4426950408889634f;
@@ -114,30 +130,42 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
     if (s0 + CH < L) fetch(s0 + CH);  // next chunk: in flight during the nst steps below
     for (int sl = 0; sl < nst; ++sl, ++step) {
       const int cur = step & 1;
-      float g[BT], p1[BT], p2[BT], p3[BT];
+      float p[BT][4];  // partial pre-activations of the unit's four gates over this lane's k-slice
 #pragma unroll
-      for (int bt = 0; bt < BT; ++bt) g[bt] = gxs[bt][sl * G4 + rowi], p1[bt] = p2[bt] = p3[bt] = 0.f;
+      for (int bt = 0; bt < BT; ++bt) {
+        const float gxv = gxs[bt][sl * G4 + rowi];  // the input contribution enters through the lane of its gate
 #pragma unroll
-      for (int k = 0; k < D; k += 4) {
+        for (int g = 0; g < 4; ++g) p[bt][g] = (g == gate) ? gxv : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KQ; k += 4) {
 #pragma unroll
         for (int bt = 0; bt < BT; ++bt) {
-          const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][bt][k]);  // broadcast
-          g[bt] = fmaf(w[k], hv.x, g[bt]);
-          p1[bt] = fmaf(w[k + 1], hv.y, p1[bt]);
-          p2[bt] = fmaf(w[k + 2], hv.z, p2[bt]);
-          p3[bt] = fmaf(w[k + 3], hv.w, p3[bt]);
+          const float4 hv = *reinterpret_cast<const float4*>(&hbuf[cur][bt][gate * KQ + k]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            p[bt][g] = fmaf(w[g][k], hv.x, p[bt][g]);
+            p[bt][g] = fmaf(w[g][k + 1], hv.y, p[bt][g]);
+            p[bt][g] = fmaf(w[g][k + 2], hv.z, p[bt][g]);
+            p[bt][g] = fmaf(w[g][k + 3], hv.w, p[bt][g]);
+          }
         }
       }
 #pragma unroll
       for (int bt = 0; bt < BT; ++bt) {
-        const float pre = (g[bt] + p1[bt]) + (p2[bt] + p3[bt]);
+        float pre = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float full = quad_xor_add<2>(quad_xor_add<1>(p[bt][g]));  // sum over the quad's four k-slices
+          pre = (g == gate) ? full : pre;
+        }
         const float t = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(sarg * pre));
         const float a = (gate == 2) ? 1.0f - 2.0f * t : t;  // own gate, activated
         const float ai = quad_bcast<0>(a), af = quad_bcast<1>(a), ag = quad_bcast<2>(a), ao = quad_bcast<3>(a);
         c[bt] = af * c[bt] + ai * ag;
         const float h = ao * tanh_fast(c[bt]);
         if (writer) {
-          hbuf[cur ^ 1][bt][e] = h;
+          hbuf[cur ^ 1][bt][hpos] = h;
           xsb[bt][sl * D + e] += h;  // residual: x <- x + LSTM(x)
         }
       }
