@@ -262,10 +262,17 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
                      int first_step, int n_run, uint64_t seed, uint64_t sample_offset, const float* z_inject,
                      int use_cache, int global_step0, void* stream);
 
-/* Process-wide tuning knob for experiments (results never change, only tiling):
- *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8  -- rows/16 per workgroup of the fused FFN;
- *   "fuse_layer" = -1 (auto) | 0 | 1 -- out-proj+LN1+FFN+LN2+next-QKV in one launch (k_layer);
- *   "attn_impl" = 0 (32x32x2-MFMA QK^T + VALU softmax/PV, default) | 1 (all VALU) | 2 (4x4x1-MFMA products). */
+/* Process-wide tuning knobs for experiments and for the test suite's kernel variants (results stay within the
+ * parity tolerance, only the kernel choice / tiling changes):
+ *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
+ *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
+ *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
+ *   "fuse_layer" = -1 (auto) | 0 | 1           out-proj+LN1+FFN+LN2+next-QKV in one launch (k_layer; default 0);
+ *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
+ *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;
+ *   "attn_impl" = 0 | 1 | 2 | 3                two-kernel path only: hybrid MFMA/VALU, all VALU, 4x4x1 MFMA, packed fp32;
+ *   "attn_qg" = 0 (heuristic) | 1 | 2 | 3      query tiles per wave;
+ *   "bench_kernel" = 0 | 1 | 2                 what ffd_bench_ffn times (FFN, k_layer without / with the QKV epilogue). */
 int ffd_tune(const char* key, int value);
 
 /* ---- introspection for benchmarks --------------------------------------- */
