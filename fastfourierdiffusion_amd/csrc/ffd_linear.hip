@@ -264,9 +264,104 @@ __global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__
   }
 }
 
+// Row-major linear with LDS-staged output (the LSTM input gates: N = 4 d): 32-row tile, n-tiles split over the
+// 4 waves with double-buffered weight fragments, the (32 x N) result staged in LDS and written as whole rows --
+// every store instruction covers 1 KiB of consecutive addresses instead of sixteen 64-byte pieces (k_linear).
+template <int D>
+__global__ __launch_bounds__(256) void k_linear_rm(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int M, int N) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  constexpr int R = 32;
+  __shared__ __align__(16) float xs[R * S];
+  __shared__ __align__(16) float stage[R * 4 * D];  // N <= 4 D
+  const int m0 = blockIdx.x * R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NT = cdiv(N, 16);
+  const float4* Wq = reinterpret_cast<const float4*>(Wp);
+  float4 wq[G], wn[G];
+  if (wave < NT) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = Wq[((size_t)wave * G + g) * 64 + lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)m0 * D);
+    const int rows_valid = min(R, M - m0);
+    for (int i4 = threadIdx.x; i4 < R * D / 4; i4 += 256) {
+      const int r = (4 * i4) / D, k = 4 * i4 - r * D;
+      const float4 v = (r < rows_valid) ? X4[i4] : float4{0.f, 0.f, 0.f, 0.f};
+      float2* dst = reinterpret_cast<float2*>(&xs[r * S + k]);
+      dst[0] = float2{v.x, v.y};
+      dst[1] = float2{v.z, v.w};
+    }
+  }
+  __syncthreads();
+  float xf[2][KS];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
+  for (int nt = wave; nt < NT; nt += 4) {
+    if (nt + 4 < NT) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) wn[g] = Wq[((size_t)(nt + 4) * G + g) * 64 + lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 q = wq[s >> 2];
+      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+      acc[0] = mfma16(a, xf[0][s], acc[0]);
+      acc[1] = mfma16(a, xf[1][s], acc[1]);
+    }
+    // D^T: lane holds columns n .. n+3 of rows (lane & 15) and 16 + (lane & 15)
+    const int n = 16 * nt + 4 * (lane >> 4);
+    if (n + 3 < N) {
+      const float4 b4 = *reinterpret_cast<const float4*>(bias + n);
+      *reinterpret_cast<float4*>(&stage[(lane & 15) * N + n]) =
+          float4{acc[0][0] + b4.x, acc[0][1] + b4.y, acc[0][2] + b4.z, acc[0][3] + b4.w};
+      *reinterpret_cast<float4*>(&stage[(16 + (lane & 15)) * N + n]) =
+          float4{acc[1][0] + b4.x, acc[1][1] + b4.y, acc[1][2] + b4.z, acc[1][3] + b4.w};
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) {
+          stage[(lane & 15) * N + n + r] = acc[0][r] + bias[n + r];
+          stage[(16 + (lane & 15)) * N + n + r] = acc[1][r] + bias[n + r];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) wq[g] = wn[g];
+  }
+  __syncthreads();
+  // copy-out: the tile's rows are consecutive in Y (row-major, ld = N): one contiguous run of rows_valid * N floats
+  const int rows_valid = min(R, M - m0);
+  const int total4 = rows_valid * N / 4;  // N % 4 == 0 (checked by the launcher)
+  float4* dst = reinterpret_cast<float4*>(Y + (size_t)m0 * N);
+  const float4* src = reinterpret_cast<const float4*>(stage);
+  for (int i = threadIdx.x; i < total4; i += 256) dst[i] = src[i];
+}
+
 hipError_t launch_linear(const float* X, const float* Wp, const float* bias, float* Y, int M, int N, int D, int ldy,
                          hipStream_t s) {
   if (M <= 0) return hipSuccess;
+  if (ldy == N && N % 4 == 0 && N <= 4 * D && (reinterpret_cast<uintptr_t>(Y) & 15) == 0 && cdiv(M, 32) >= 512) {
+    // large row-major outputs: LDS-staged whole-row stores
+    dim3 grid(cdiv(M, 32)), block(256);
+    switch (D) {
+#define X(d) \
+      case d: hipLaunchKernelGGL(k_linear_rm<d>, grid, block, 0, s, X, Wp, bias, Y, M, N); break;
+      FFD_D_LIST(X)
+#undef X
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   dim3 grid(cdiv(M, 64)), block(256);
   switch (D) {
 #define X(d) \

@@ -348,6 +348,24 @@ def test_model_full_batch_properties(ffd):
     assert rel_err(out[100:104], ref) < TOL_SCORE
 
 
+def test_lstm_full_batch_properties(ffd):
+    """BASELINE configs[3] shape at B=128 (32 128 rows: the LDS-staged row-major gate GEMM and two recurrence
+    workgroups per CU are in play): sample independence + agreement of a slice with the oracle."""
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    B = 128
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4343)))
+    out = m(batch_of(x.cuda(), 0.45)).cpu()
+    assert torch.isfinite(out).all()
+    for b in (0, 63, 127):
+        one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
+        assert rel_err(out[b:b + 1], one) < 2e-6, b
+    t = torch.full((2,), 0.45, dtype=torch.float32)
+    ref = O.lstm_score_forward(x[40:42], t, sd, c["NL"])
+    assert rel_err(out[40:42], ref) < TOL_SCORE
+
+
 def test_errors_are_loud(ffd):
     from fastfourierdiffusion_amd._native import FFDError
     from fastfourierdiffusion_amd.models.score_models import ScoreModule
