@@ -143,26 +143,32 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ We, const float* __restrict__ be,
                         const float* __restrict__ pos, const float* __restrict__ temb, float* __restrict__ h,
                         unsigned total4, int L, int C, int D) {
-  // one float4 of h per thread (D % 4 == 0); 32-bit index math only
+  // The (D x C) embedder weight is staged transposed in LDS ([c][j]), so the C weights of an output float4 are C
+  // aligned 16-byte LDS reads instead of 4 C scattered global loads.  One float4 of h per thread and iteration
+  // (D % 4 == 0); 32-bit index math only; same operation order as before the staging.
+  extern __shared__ __align__(16) float wt[];  // C * D floats
+  for (int i = threadIdx.x; i < C * D; i += blockDim.x) {
+    const int c = i / D, j = i - c * D;
+    wt[i] = We[j * C + c];
+  }
+  __syncthreads();
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
     const unsigned row = (4u * i4) / (unsigned)D;
     const int j = (int)(4u * i4 - row * (unsigned)D);
     const int l = (int)(row % (unsigned)L);
     const float* x = X + (size_t)row * C;
-    float v[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) v[q] = be[j + q];
+    float4 v = float4{be[j], be[j + 1], be[j + 2], be[j + 3]};
     for (int c = 0; c < C; ++c) {
       const float xc = x[c];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = fmaf(xc, We[(j + q) * C + c], v[q]);
+      const float4 w4 = *reinterpret_cast<const float4*>(&wt[c * D + j]);
+      v.x = fmaf(xc, w4.x, v.x), v.y = fmaf(xc, w4.y, v.y), v.z = fmaf(xc, w4.z, v.z), v.w = fmaf(xc, w4.w, v.w);
     }
     if (pos) {
       const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)l * D + j);
-      v[0] += p.x, v[1] += p.y, v[2] += p.z, v[3] += p.w;
+      v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
     }
     const float4 t = *reinterpret_cast<const float4*>(temb + j);
-    reinterpret_cast<float4*>(h)[i4] = float4{v[0] + t.x, v[1] + t.y, v[2] + t.z, v[3] + t.w};
+    reinterpret_cast<float4*>(h)[i4] = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
   }
 }
 
@@ -170,8 +176,10 @@ hipError_t launch_embed(const float* X, const float* We, const float* be, const 
                         float* h, int B, int L, int C, int D, hipStream_t s) {
   const unsigned total4 = (unsigned)((size_t)B * L * D / 4);
   unsigned blocks = (total4 + 255) / 256;
-  if (blocks > 16384) blocks = 16384;
-  hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, h, total4, L, C, D);
+  if (blocks > 4096) blocks = 4096;  // grid-stride: the weight staging is amortised over >= a few rows per thread
+  const size_t lds = (size_t)C * D * sizeof(float);
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), lds, s, X, We, be, pos, temb, h, total4, L, C, D);
   return hipGetLastError();
 }
 
@@ -225,13 +233,24 @@ hipError_t launch_renorm_rows_once(float* W, int rows, int D, float max_norm, hi
 // ---------------------------------------------------------------------------
 __global__ void k_unembed(const float* __restrict__ h, const float* __restrict__ Wu, const float* __restrict__ bu,
                           float* __restrict__ score, int M, int C, int D) {
+  // The row's D values are read once into registers (lane `sub` of the row's 16 holds k = sub, sub+16, ...), the
+  // (C x D) weight sits in LDS; per channel: <= 8 FMAs and a 16-lane xor reduction.  D <= 128.
+  extern __shared__ float wl[];  // C * D
+  for (int i = threadIdx.x; i < C * D; i += blockDim.x) wl[i] = Wu[i];
+  __syncthreads();
+  constexpr int NI = 8;
   const int sub = threadIdx.x & 15;
   const int rows_per_block = blockDim.x >> 4;
   for (int row = blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < M; row += gridDim.x * rows_per_block) {
     const float* hr = h + (size_t)row * D;
+    float hv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) hv[i] = (sub + 16 * i < D) ? hr[sub + 16 * i] : 0.f;
     for (int c = 0; c < C; ++c) {
       float acc = 0.f;
-      for (int k = sub; k < D; k += 16) acc = fmaf(hr[k], Wu[c * D + k], acc);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (16 * i < D) acc = fmaf(hv[i], (sub + 16 * i < D) ? wl[c * D + sub + 16 * i] : 0.f, acc);
       acc += __shfl_xor(acc, 8, 16);
       acc += __shfl_xor(acc, 4, 16);
       acc += __shfl_xor(acc, 2, 16);
@@ -243,9 +262,10 @@ __global__ void k_unembed(const float* __restrict__ h, const float* __restrict__
 
 hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, float* score, int M, int C, int D,
                           hipStream_t s) {
+  if (D > 128 || (size_t)C * D * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
   int blocks = cdiv(M, 16);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_unembed, dim3(blocks), dim3(256), 0, s, h, Wu, bu, score, M, C, D);
+  hipLaunchKernelGGL(k_unembed, dim3(blocks), dim3(256), (size_t)C * D * sizeof(float), s, h, Wu, bu, score, M, C, D);
   return hipGetLastError();
 }
 
