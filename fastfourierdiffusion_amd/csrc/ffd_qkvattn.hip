@@ -12,7 +12,8 @@
 // consecutive k of its token per 16-wide chunk (float4), the weight pack uses the same k permutation --
 // and the softmax scale log2(e)/sqrt(hd) is folded into the q rows of the pack.
 // Phase 2 (attention): identical to k_attention_pk (ffd_attn.hip): S^T tiles on v_mfma_f32_32x32x2_f32 with the
-// stale-max reference riding on contraction dim hd, packed-fp32 softmax / P.V, V rows pipelined from LDS.
+// stale-max reference riding on contraction dim hd (skipped while it is zero), packed-fp32 softmax / P.V, V rows
+// pipelined from LDS.
 //
 // E2-CRF cache modes (cached_transformer.py:237-305): `n_own` leading tokens take K/V from the projection,
 // the rest from the shared tables (kt/vt != NULL); PURE (n_own = 0) runs with the q-only weight pack; in
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   constexpr int C16 = D / 16;           // full 16-wide k chunks
   constexpr int REM = (D % 16) / 4;     // remaining k-steps (k = 16*C16 + 4 i + q)
   constexpr int S4 = (D + 15) / 16;     // float4 groups of packed weight per (h, ct)
-  constexpr float T = 8.0f;
+  constexpr float T = 64.0f;  // scores (log2 domain) may sit this far from the reference before it is refreshed
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwaves = blockDim.x >> 6;
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   const int d = D;
   for (int qt0 = wave * QG; qt0 < QT; qt0 += nwaves * QG) {
     float qf[QG][KSX], mref[QG];
+    bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
     f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -316,7 +318,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int g = 0; g < QG; ++g) {
         f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < KSX; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        for (int s = 0; s < KSX; ++s) {
+          if (HD % 2 == 0 && s == SX && !ref_on) continue;  // even hd: that step carries nothing but -m_ref = 0
+          z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        }
         sc[g] = z;
       }
       const int kbase = 32 * t + 4 * half;
@@ -339,7 +344,11 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
         bm = __builtin_fmaxf(bm, sc[g][15]);
         const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
-        if (t == 0 || bmx > T) {
+        // m_ref starts at 0 and usually stays there: |scores| <= 64 (log2 domain) neither overflow nor lose the row
+        // to underflow, and the factor 2^-m_ref cancels in the normalisation whatever it is.
+        const bool refresh = (t == 0) ? (fabsf(bmx) > T) : (bmx > T);
+        if (__builtin_amdgcn_ballot_w64(refresh) != 0) ref_on = true;
+        if (refresh) {
           const float delta = bmx;
           mref[g] += delta;
           if (t != 0) {
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   constexpr int S4 = (D + 15) / 16;
   constexpr int NW = 2 * HPW;           // waves per workgroup
   constexpr int MAXT = 3;               // token tiles per wave: Lp <= 192 -> 12 tiles over >= 4 waves
-  constexpr float T = 8.0f;
+  constexpr float T = 64.0f;  // scores (log2 domain) may sit this far from the reference before it is refreshed
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b, hg;
@@ -609,6 +618,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   const int QT = KT;
   for (int qt0 = gw * QG; qt0 < QT; qt0 += 2 * QG) {
     float qf[QG][KSX], mref[QG];
+    bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
     f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -637,7 +647,10 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       for (int g = 0; g < QG; ++g) {
         f32x16 z = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < KSX; ++s) z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        for (int s = 0; s < KSX; ++s) {
+          if (HD % 2 == 0 && s == SX && !ref_on) continue;  // even hd: that step carries nothing but -m_ref = 0
+          z = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[g][s], z, 0, 0, 0);
+        }
         sc[g] = z;
       }
       const int kbase = 32 * t + 4 * half;
@@ -660,7 +673,11 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
         bm = __builtin_fmaxf(bm, sc[g][15]);
         const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
-        if (t == 0 || bmx > T) {
+        // m_ref starts at 0 and usually stays there: |scores| <= 64 (log2 domain) neither overflow nor lose the row
+        // to underflow, and the factor 2^-m_ref cancels in the normalisation whatever it is.
+        const bool refresh = (t == 0) ? (fabsf(bmx) > T) : (bmx > T);
+        if (__builtin_amdgcn_ballot_w64(refresh) != 0) ref_on = true;
+        if (refresh) {
           const float delta = bmx;
           mref[g] += delta;
           if (t != 0) {
