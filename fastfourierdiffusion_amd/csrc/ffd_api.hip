@@ -63,7 +63,7 @@ struct ffd_ctx {
   std::vector<float> G_host;
   // workspace
   int ws_B = 0;
-  float *h0 = nullptr, *h1 = nullptr, *qkv = nullptr, *attn = nullptr, *score = nullptr, *kvtmp = nullptr;
+  float *h0 = nullptr, *h1 = nullptr, *qkv = nullptr, *attn = nullptr, *score = nullptr;
   float *temb1 = nullptr, *temb_tab = nullptr, *ts_dev = nullptr;
   int temb_cap = 0;
   std::vector<float> ts_host;
@@ -479,7 +479,6 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
     if ((rc = dev_alloc(ctx, &ctx->h1, M * d))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->qkv, M * 3 * d))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->attn, M * d))) return rc;
-    if (!ctx->kvtmp && (rc = dev_alloc(ctx, &ctx->kvtmp, (size_t)m.max_len * 2 * d))) return rc;
   } else {
     if ((rc = dev_alloc(ctx, &ctx->qkv, M * 4 * d))) return rc;  // gate pre-activations gx
   }
