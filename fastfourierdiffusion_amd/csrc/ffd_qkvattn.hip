@@ -747,6 +747,7 @@ static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt,
   const int KT = (L + 31) / 32;
   const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256) * sizeof(float);
   auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
+  if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
   hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
                      n_own, q_only);
   return hipGetLastError();
@@ -775,6 +776,7 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
   const size_t lds = (size_t)KT * 32 * (8 + 4 * KST) * sizeof(float);
   int nwaves = cdiv(KT, QG);
   if (nwaves > 4) nwaves = 4;
+  if (cdiv(2 * KT, nwaves) > 8) return hipErrorInvalidValue;  // the projection loop is unrolled for <= 8 token tiles per wave
   hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x, awp, kt, vt,
                      kt_out, vt_out, out, B, L, n_own, q_only);
   return hipGetLastError();
