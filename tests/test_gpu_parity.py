@@ -362,6 +362,36 @@ def test_attention_large_logits_vs_oracle(ffd, scale, variant):
     assert rel_err(out, ref) < (TOL_SCORE if scale < 10 else 1e-3), scale
 
 
+# every (d_model, head_dim) pair with kernels in this build, at lengths that exercise 1..many key tiles, odd / even L
+_SHAPES = [(72, 12, 187), (60, 12, 50), (48, 12, 33), (64, 8, 100), (32, 4, 64), (16, 4, 20), (24, 8, 45), (24, 4, 20),
+           (8, 4, 31), (72, 12, 300), (48, 12, 192), (60, 12, 193), (64, 8, 512)]
+
+
+@pytest.mark.parametrize("shape", _SHAPES, ids=lambda s: f"d{s[0]}h{s[1]}L{s[2]}")
+def test_supported_shapes_vs_oracle(ffd, shape, variant):
+    """No-cache and cached (FULL -> PURE -> MIXED) evaluations against the oracle for every supported head shape."""
+    if variant not in ("auto", "unfused"):
+        pytest.skip("shape sweep runs on the default and the two-kernel paths")
+    d, H, L = shape
+    C, NL, B = 2, 2, 3
+    c = dict(kind="transformer", d=d, H=H, NL=NL, L=L, C=C, sde="vp", sde_kwargs=cases.VP, fourier=True, wseed=600 + d + L)
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 9000 + d)))
+    t = torch.full((B,), 0.7, dtype=torch.float32)
+    out = m(batch_of(x.cuda(), 0.7)).cpu()
+    assert rel_err(out, O.score_forward(x, t, sd, NL, H)) < TOL_SCORE
+    m.enable_caching()
+    m.cache.reset()
+    table = O.KVTable(NL, L)
+    for j, n in enumerate([L, 0, min(10, L), 0]):
+        xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 9100 + d + j)))
+        ref = O.score_forward(xj, t, sd, NL, H, table, list(range(n)))
+        got = m(batch_of(xj.cuda(), 0.7), recompute_tokens=set(range(n)), step=j)
+        assert rel_err(got.cpu(), ref) < TOL_SCORE, (j, n)
+    m.disable_caching()
+
+
 def test_model_full_batch_properties(ffd):
     """BASELINE configs[1] batch (B=512): sample independence (a size-independent
     property of the path) -- every sample of a big batch equals its own B=1 evaluation
