@@ -678,3 +678,37 @@ def test_mlp_trajectory_vs_oracle(ffd):
                    fourier_noise_scaling=True, num_samples=2 * B, batch_size=B, num_steps=N, noise=noise)
     assert tuple(out.shape) == (2 * B, L, C)
     assert rel_err(out, ref) < TOL_TRAJ
+
+
+# ------------------------------------------ sampler option matrix vs the oracle ----
+@pytest.mark.parametrize("sde", ["vp", "ve"])
+@pytest.mark.parametrize("fourier", [True, False])
+@pytest.mark.parametrize("use_cache", [False, True])
+@pytest.mark.parametrize("fresca", [False, True])
+def test_sampler_option_matrix_vs_oracle(ffd, sde, fourier, use_cache, fresca):
+    """Every combination of scheduler, noise scaling, E2-CRF cache (R=100 so that a refresh step falls inside) and
+    FreSca on the small model, two batches (Q3 cache semantics), against the oracle's sampler on the same draws."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    base = next(c for c in cases.MODEL_CASES if c["name"] == "small")
+    c = dict(base, sde=sde, sde_kwargs=cases.VP if sde == "vp" else cases.VE, fourier=fourier)
+    m, sch = make_model(ffd, c)
+    sd = make_sd(c)
+    B, L, C, N, ns = 2, c["L"], c["C"], 104, 4
+    fk = dict(low_scale=0.9, high_scale=1.4, cutoff_ratio=0.5, cutoff_strategy="energy") if fresca else None
+    fres = {} if fk is None else dict(use_fresca=True, fresca_low_scale=fk["low_scale"], fresca_high_scale=fk["high_scale"],
+                                      fresca_cutoff_ratio=fk["cutoff_ratio"], fresca_cutoff_strategy=fk["cutoff_strategy"])
+    ck = {"K": 3, "R": 100}
+    sampler = DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=use_cache, cache_kwargs=dict(ck),
+                               z_chunk_steps=37, **fres)
+    nb = ns // B
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), nb * (N + 1), 555))
+    out = sampler.sample(num_samples=ns, num_diffusion_steps=N)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), 555))
+    ref = O.sample(sd, kind="transformer", n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=sde,
+                   sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=fourier, num_samples=ns, batch_size=B, num_steps=N,
+                   noise=noise, use_cache=use_cache, K=ck["K"], R=ck["R"], fresca_kwargs=fk)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out, ref) < 2 * TOL_TRAJ, rel_err(out, ref)
+    if use_cache:
+        m.disable_caching()
