@@ -148,3 +148,17 @@ MLP_CASES = [
     dict(name="nasa_mlp", kind="mlp", d=72, d_mlp=512, NL=3, L=251, C=4, H=1, B=7, wseed=51, xseed=41),      # L*C % 4 == 0
     dict(name="odd_mlp", kind="mlp", d=13, d_mlp=70, NL=1, L=9, C=2, H=1, B=33, wseed=52, xseed=42),         # ragged everything
 ]
+
+# More sampler combinations pinned against the reference (g11): VE / time-domain with the cache and FreSca together
+EXTRA_TRAJ_CASES = [
+    dict(name="x_ve_cache_fresca", **_SMALL, sde="ve", sde_kwargs=VE, fourier=True, B=2, num_samples=4, N=104,
+         use_cache=True, cache_kwargs={"K": 3, "R": 100}, wseed=42, zseed=71,
+         fresca=dict(low_scale=0.9, high_scale=1.4, cutoff_ratio=0.5, cutoff_strategy="energy")),
+    dict(name="x_vp_time_cache", **_SMALL, sde="vp", sde_kwargs=VP, fourier=False, B=2, num_samples=4, N=104,
+         use_cache=True, cache_kwargs={"K": 3, "R": 100}, wseed=42, zseed=72),
+    dict(name="x_ve_time_fresca_spatial", **_SMALL, sde="ve", sde_kwargs=VE, fourier=False, B=3, num_samples=3, N=20,
+         use_cache=False, wseed=42, zseed=73,
+         fresca=dict(low_scale=1.1, high_scale=0.8, cutoff_ratio=0.3, cutoff_strategy="spatial")),
+    dict(name="x_reftest_vp_cache", **_REFTEST, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2, N=12,
+         use_cache=True, cache_kwargs={}, wseed=43, zseed=74),
+]

@@ -135,12 +135,37 @@ def gen_freqca(ns) -> None:
     np.savez_compressed(os.path.join(OUT, "g10_freqca.npz"), **g)
 
 
+def gen_extra_traj(ns) -> None:
+    """G11: further sampler combinations (VE / time domain x cache x FreSca), each with the timestep grid used."""
+    g = {}
+    for c in cases.EXTRA_TRAJ_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+        nb = max(1, c["num_samples"] // B)
+        stream = synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"])
+        fk = c.get("fresca")
+        fres = {} if fk is None else dict(use_fresca=True, fresca_low_scale=fk["low_scale"],
+                                          fresca_high_scale=fk["high_scale"], fresca_cutoff_ratio=fk["cutoff_ratio"],
+                                          fresca_cutoff_strategy=fk["cutoff_strategy"])
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
+                                      cache_kwargs=dict(c.get("cache_kwargs", {})), **fres)
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        g[c["name"]] = out.numpy()
+        g[c["name"] + "_ts"] = sch.timesteps.numpy().copy()
+        print(c["name"], out.shape, float(out.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "g11_extra_traj.npz"), **g)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
     if "--only-freqca" in sys.argv:  # regenerate just G10 (the 1000-step trajectories take minutes)
         gen_freqca(ns)
+        return
+    if "--only-extra" in sys.argv:  # just G11
+        gen_extra_traj(ns)
         return
     meta = {"torch": torch.__version__}
 
@@ -266,6 +291,7 @@ def main() -> None:
     np.savez_compressed(os.path.join(OUT, "g9_gate.npz"), **g)
 
     gen_freqca(ns)
+    gen_extra_traj(ns)
 
     with open(os.path.join(OUT, "META.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from the unmodified reference at /root/reference\n")

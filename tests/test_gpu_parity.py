@@ -712,3 +712,33 @@ def test_sampler_option_matrix_vs_oracle(ffd, sde, fourier, use_cache, fresca):
     assert rel_err(out, ref) < 2 * TOL_TRAJ, rel_err(out, ref)
     if use_cache:
         m.disable_caching()
+
+
+@pytest.mark.parametrize("c", cases.EXTRA_TRAJ_CASES, ids=lambda c: c["name"])
+def test_extra_traj_golden(ffd, golden, c):
+    """G11: VE / time-domain x cache x FreSca combinations against the unmodified reference's output."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    m, sch = make_model(ffd, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    fk = c.get("fresca")
+    fres = {} if fk is None else dict(use_fresca=True, fresca_low_scale=fk["low_scale"], fresca_high_scale=fk["high_scale"],
+                                      fresca_cutoff_ratio=fk["cutoff_ratio"], fresca_cutoff_strategy=fk["cutoff_strategy"])
+    sampler = DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
+                               cache_kwargs=dict(c.get("cache_kwargs", {})), z_chunk_steps=41, **fres)
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    g = golden["g11_extra_traj"]
+    ts_golden = torch.from_numpy(g[c["name"] + "_ts"].copy())
+    orig = sch.set_timesteps
+
+    def pinned(n):
+        orig(n)
+        sch.timesteps = ts_golden
+        sch.step_size = ts_golden[0] - ts_golden[1]
+
+    sch.set_timesteps = pinned
+    out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+    assert rel_err(out, g[c["name"]]) < TOL_TRAJ, rel_err(out, g[c["name"]])
+    if c["use_cache"]:
+        m.disable_caching()

@@ -226,3 +226,20 @@ def test_freqca_state_golden(golden, c):
         assert len(st.high_history) == int(g[f"{name}_stats"][0])
         pred = st.low + O.predict_hermite(st.high_history, st.t_history, c["t_pred"], ck.get("hermite_order", 3))
         assert rel_err(pred, g[f"{name}_pred"]) < TOL_HERMITE
+
+
+# ---- G11: further sampler combinations pinned against the reference ----
+@pytest.mark.parametrize("c", cases.EXTRA_TRAJ_CASES, ids=lambda c: c["name"])
+def test_extra_traj_golden(golden, c):
+    sd = make_sd(c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    ck = c.get("cache_kwargs", {})
+    out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=c["sde"],
+                   sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"], num_samples=c["num_samples"],
+                   batch_size=B, num_steps=N, noise=noise, use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10),
+                   fresca_kwargs=c.get("fresca"))
+    ref = golden["g11_extra_traj"][c["name"]]
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
