@@ -123,6 +123,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cache-ratio side measurements")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ffd_tune (experiments)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and the barrier / max-reduce "
+                         "run over gloo (RCCL refuses two ranks on one device); the reported number is meaningless")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,6 +133,8 @@ def main() -> None:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs; there is no CPU path"
+    if args.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
@@ -138,7 +143,10 @@ def main() -> None:
 
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from fastfourierdiffusion_amd import _native as N
     from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
@@ -183,7 +191,7 @@ def main() -> None:
     run_steps(model, sampler, X, ts_c, n_total, step_size, first, K, use_cache, stream, offset)
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = reduce_max_seconds(elapsed, device)
+    elapsed = reduce_max_seconds(elapsed, None if args.rehearse_one_gpu else device)
     assert torch.isfinite(X).all(), "non-finite samples"
     ms_per_step = elapsed / K * 1e3
     value = world * B / (1000.0 * (elapsed / K))
