@@ -64,6 +64,7 @@ def __getattr__(name):  # lazy top-level conveniences
         "VEScheduler": ("fastfourierdiffusion_amd.schedulers.sde", "VEScheduler"),
         "E2CRFCache": ("fastfourierdiffusion_amd.utils.caching", "E2CRFCache"),
         "DiffusableBatch": ("fastfourierdiffusion_amd.utils.dataclasses", "DiffusableBatch"),
+        "benchmark_sampling": ("fastfourierdiffusion_amd.benchmark", "benchmark_sampling"),
         "dft": ("fastfourierdiffusion_amd.utils.fourier", "dft"),
         "idft": ("fastfourierdiffusion_amd.utils.fourier", "idft"),
     }

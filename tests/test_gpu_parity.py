@@ -742,3 +742,26 @@ def test_extra_traj_golden(ffd, golden, c):
     assert rel_err(out, g[c["name"]]) < TOL_TRAJ, rel_err(out, g[c["name"]])
     if c["use_cache"]:
         m.disable_caching()
+
+
+def test_benchmark_sampling_harness(ffd):
+    """T1: the cmd/benchmark_cache.py harness -- same keys, the reference's batching (B=1 -> num_samples batches),
+    stats visible on the cache object the harness reads (Q5: zero hits on the sampler-visible object after the
+    second enable_caching), cache on/off outputs on the same noise stay finite and close."""
+    from fastfourierdiffusion_amd.benchmark import benchmark_sampling
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "small")
+    m, _ = make_model(ffd, c)
+    torch.manual_seed(0)
+    off = benchmark_sampling(m, num_samples=3, num_diffusion_steps=12, use_cache=False)
+    torch.manual_seed(0)
+    on = benchmark_sampling(m, num_samples=3, num_diffusion_steps=12, use_cache=True, cache_kwargs={})
+    for r in (off, on):
+        assert set(r) == {"elapsed_time", "samples", "cache_stats", "num_samples", "num_diffusion_steps"}
+        assert tuple(r["samples"].shape) == (3, c["L"], c["C"]) and r["samples"].device.type == "cpu"
+        assert torch.isfinite(r["samples"]).all() and r["elapsed_time"] > 0
+    assert off["cache_stats"] == {}
+    assert {"cache_hit_ratio", "cache_ratio", "recompute_count", "cache_hit_count", "current_step"} <= set(on["cache_stats"])
+    fr = benchmark_sampling(m, num_samples=2, num_diffusion_steps=8, use_cache=True, cache_kwargs={}, use_fresca=True)
+    assert torch.isfinite(fr["samples"]).all()
+    m.disable_caching()
