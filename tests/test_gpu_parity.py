@@ -765,3 +765,20 @@ def test_benchmark_sampling_harness(ffd):
     fr = benchmark_sampling(m, num_samples=2, num_diffusion_steps=8, use_cache=True, cache_kwargs={}, use_fresca=True)
     assert torch.isfinite(fr["samples"]).all()
     m.disable_caching()
+
+
+@pytest.mark.parametrize("case", cases.ANALYZE_CASES, ids=lambda c: c[0])
+def test_analyze_frequency_content_golden(ffd, golden, case):
+    """fresca.py:271-311 incl. its (n_freq, 1) mask broadcasting quirk; magnitudes from the device spectrum."""
+    from fastfourierdiffusion_amd.utils.fresca import analyze_frequency_content
+
+    name, B, L, C, seed, ratio = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed))).cuda()
+    r = analyze_frequency_content(x, ratio)
+    got = np.array([float(r[k]) for k in ("low_energy", "high_energy", "total_energy", "low_energy_ratio",
+                                          "high_energy_ratio")])
+    np.testing.assert_allclose(got, golden["g11_extra_traj"][name], rtol=2e-5)
+    if B not in (1, L // 2 + 1):
+        return
+    with pytest.raises(RuntimeError):  # the reference's own shape error for other batch sizes
+        analyze_frequency_content(torch.zeros(2, L, C, device="cuda"), ratio)

@@ -264,3 +264,25 @@ def test_shard_plan_two_ranks_gloo(tmp_path):
 
     res = json.loads(outs[0].strip().splitlines()[-1])
     assert res["ranges"] == [[0, 501], [501, 500]] and res["tmax"] == 1.5
+
+
+def test_create_frequency_masks_golden():
+    """fresca.py:13-108: pure host helper of the fdiff.utils.fresca mirror, pinned against the reference (g11)."""
+    import numpy as np
+    import torch
+
+    from conftest import load_golden
+    from fastfourierdiffusion_amd.utils import synthetic
+    from fastfourierdiffusion_amd.utils.fresca import create_frequency_masks
+    from oracle import cases
+
+    g = load_golden("g11_extra_traj.npz")
+    for (name, shape, ratio, strat, seed) in cases.MASK_CASES:
+        spec = None if seed is None else torch.from_numpy(np.abs(next(synthetic.noise_stream(shape, 1, seed))))
+        lo, hi = create_frequency_masks(shape, ratio, strat, spec)
+        np.testing.assert_array_equal(lo.numpy(), g[name + "_low"])
+        np.testing.assert_array_equal(hi.numpy(), g[name + "_high"])
+    with pytest.raises(ValueError):
+        create_frequency_masks((8,), 0.5, "energy", None)
+    with pytest.raises(ValueError):
+        create_frequency_masks((2, 2, 2), 0.5)
