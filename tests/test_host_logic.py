@@ -286,3 +286,18 @@ def test_create_frequency_masks_golden():
         create_frequency_masks((8,), 0.5, "energy", None)
     with pytest.raises(ValueError):
         create_frequency_masks((2, 2, 2), 0.5)
+
+
+def test_hermite_polynomials_known_answers():
+    """fourier.py:341-394: H0 = 1, H1 = 2s, H2 = 4s^2 - 2, H3 = 8s^3 - 12s, then H_{n+1} = 2s H_n - 2n H_{n-1}."""
+    from fastfourierdiffusion_amd.utils.fourier import hermite_polynomials
+
+    s = torch.tensor([-1.0, -0.5, 0.0, 0.25, 1.0])
+    H = hermite_polynomials(s, 4)
+    assert H.shape == (5, 5)
+    torch.testing.assert_close(H[0], torch.ones(5))
+    torch.testing.assert_close(H[1], 2 * s)
+    torch.testing.assert_close(H[2], 4 * s ** 2 - 2)
+    torch.testing.assert_close(H[3], 8 * s ** 3 - 12 * s)
+    torch.testing.assert_close(H[4], 16 * s ** 4 - 48 * s ** 2 + 12)
+    assert hermite_polynomials(torch.zeros(2, 3), 2).shape == (3, 2, 3)
