@@ -826,6 +826,21 @@ int ffd_hermite_predict(const float* history, const double* timesteps, double ta
   return launch_weighted_sum(history, w, out, K, n, (hipStream_t)stream) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
 }
 
+int ffd_row_delta_norm_mean(const float* a, const float* b, float* work, int rows, int D, double* mean_out,
+                            void* stream) {
+  if (!a || !b || !work || !mean_out || rows < 1 || D < 1) return FFD_ERR_INVALID;
+  const int nblocks = std::min(256, cdiv(rows, 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (launch_row_delta_norm(a, b, work, nblocks, rows, D, s) != hipSuccess) return FFD_ERR_HIP;
+  float part[256];
+  if (hipMemcpyAsync(part, work, sizeof(float) * nblocks, hipMemcpyDeviceToHost, s) != hipSuccess) return FFD_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) return FFD_ERR_HIP;
+  double tot = 0.0;
+  for (int i = 0; i < nblocks; ++i) tot += (double)part[i];
+  *mean_out = tot / (double)rows;
+  return FFD_OK;
+}
+
 int ffd_cache_crf_capture(ffd_ctx* ctx, const ffd_crf_capture_cfg* cfg) {
   if (!ctx) return FFD_ERR_INVALID;
   if (!cfg) {

@@ -438,4 +438,31 @@ hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* ou
   return hipGetLastError();
 }
 
+// compute_event_intensity's reduction (caching.py:546-556): mean over rows of || a_r - b_r ||_2.
+// One wave per row, per-block partial sums in a fixed order (deterministic); the host adds the <= 256 partials.
+__global__ __launch_bounds__(256) void k_row_delta_norm(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ partial, int rows, int D) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    float ss = 0.f;
+    for (int k = lane; k < D; k += 64) {
+      const float dlt = fabsf(a[(size_t)r * D + k] - b[(size_t)r * D + k]);
+      ss = fmaf(dlt, dlt, ss);
+    }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    acc += sqrtf(ss);
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+hipError_t launch_row_delta_norm(const float* a, const float* b, float* partial, int nblocks, int rows, int D,
+                                 hipStream_t s) {
+  hipLaunchKernelGGL(k_row_delta_norm, dim3(nblocks), dim3(256), 0, s, a, b, partial, rows, D);
+  return hipGetLastError();
+}
+
 }  // namespace ffd

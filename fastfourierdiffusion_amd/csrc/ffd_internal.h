@@ -150,6 +150,8 @@ hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inve
 hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
                                  hipStream_t s);
 hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, int C, hipStream_t s);
+hipError_t launch_row_delta_norm(const float* a, const float* b, float* partial, int nblocks, int rows, int D,
+                                 hipStream_t s);
 hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* out, int K, size_t n, hipStream_t s);
 // FreSca spectral scaling of a (B,L,C) score; work: B*(L/2+1) + 1 floats; strategy 0 spatial, 1 energy
 hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,

@@ -219,6 +219,12 @@ int ffd_hermite_predict(const float* history, const double* timesteps, double ta
  * callers with time-domain input run ffd_dft first (apply_dft=True). */
 int ffd_spectral_density(const float* xf, float* out, int B, int L, int C, void* stream);
 
+/* The reduction of E2CRFCache.compute_event_intensity (caching.py:546-556): *mean_out = mean over the `rows` rows of
+ * || a_r - b_r ||_2 for two device tensors (rows, D).  `work` = 256 device floats.  Synchronises `stream` (the
+ * reference reads the value with .item()). */
+int ffd_row_delta_norm_mean(const float* a, const float* b, float* work, int rows, int D, double* mean_out,
+                            void* stream);
+
 /* CRF capture inside ffd_sample_batch (the reference's cache.update_crf call, sampler.py:70-73):
  * on cached steps whose global step g satisfies g % every == 0 the (NL, L, d) CRF (score_models.py:181-194)
  * is written to ring slot (g / every) % n_slots; `last` receives the CRF of the last step of each

@@ -782,3 +782,18 @@ def test_analyze_frequency_content_golden(ffd, golden, case):
         return
     with pytest.raises(RuntimeError):  # the reference's own shape error for other batch sizes
         analyze_frequency_content(torch.zeros(2, L, C, device="cuda"), ratio)
+
+
+def test_compute_event_intensity_vs_reference_formula(ffd):
+    """caching.py:524-559: min(1, mean_{layer,token} ||crf - crf_prev||_2 / tau_0); 1.0 / 0.1 without a previous CRF."""
+    from fastfourierdiffusion_amd.utils.caching import E2CRFCache
+
+    cache = E2CRFCache(num_layers=3, max_len=20, device=torch.device("cuda"), tau_0=0.5)
+    a = torch.from_numpy(next(synthetic.noise_stream((3, 20, 24), 1, 1201)))
+    b = a + 0.01 * torch.from_numpy(next(synthetic.noise_stream((3, 20, 24), 1, 1202)))
+    assert cache.compute_event_intensity(a.cuda(), 0) == 1.0 and cache.compute_event_intensity(a.cuda(), 3) == 0.1
+    cache.crf_cache = a.cuda()
+    want = min(1.0, torch.norm(torch.abs(b - a), dim=-1).mean().item() / 0.5)
+    got = cache.compute_event_intensity(b.cuda(), 4)
+    assert abs(got - want) < 2e-6 * max(1.0, want)
+    assert cache.compute_event_intensity((a + 100.0).cuda(), 5) == 1.0  # clipped
