@@ -364,7 +364,7 @@ def test_attention_large_logits_vs_oracle(ffd, scale, variant):
 
 # every (d_model, head_dim) pair with kernels in this build, at lengths that exercise 1..many key tiles, odd / even L
 _SHAPES = [(72, 12, 187), (60, 12, 50), (48, 12, 33), (64, 8, 100), (32, 4, 64), (16, 4, 20), (24, 8, 45), (24, 4, 20),
-           (8, 4, 31), (72, 12, 300), (48, 12, 192), (60, 12, 193), (64, 8, 512)]
+           (8, 4, 31), (72, 12, 300), (48, 12, 192), (60, 12, 193), (64, 8, 512), (72, 12, 512), (24, 8, 500)]
 
 
 @pytest.mark.parametrize("shape", _SHAPES, ids=lambda s: f"d{s[0]}h{s[1]}L{s[2]}")
