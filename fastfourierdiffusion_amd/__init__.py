@@ -9,6 +9,7 @@ sub-modules mirror the reference's import paths
     fdiff.utils.caching.E2CRFCache               -> .utils.caching
     fdiff.utils.fourier.{dft,idft,spectral_density,frequency_decompose_*,predict_hermite} -> .utils.fourier
     fdiff.utils.dataclasses.DiffusableBatch      -> .utils.dataclasses
+    fdiff.utils.extraction.{get_best_checkpoint,get_model_type,flatten_config} -> .utils.extraction
 
 and ``install_as_fdiff()`` registers them under the ``fdiff.*`` names so that existing
 scripts and Hydra ``_target_`` strings resolve unchanged.  All arithmetic runs in
@@ -33,6 +34,7 @@ _MIRROR = {
     "fdiff.utils.fourier": "fastfourierdiffusion_amd.utils.fourier",
     "fdiff.utils.fresca": "fastfourierdiffusion_amd.utils.fresca",
     "fdiff.utils.dataclasses": "fastfourierdiffusion_amd.utils.dataclasses",
+    "fdiff.utils.extraction": "fastfourierdiffusion_amd.utils.extraction",
 }
 
 

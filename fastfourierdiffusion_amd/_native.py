@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libffd.so")
 
 FFD_MODEL_TRANSFORMER, FFD_MODEL_LSTM, FFD_MODEL_MLP = 0, 1, 2
 FFD_SDE_VP, FFD_SDE_VE = 0, 1
+# kernel classes (include/ffd.h FFD_K_*)
+K_FFN, K_ATTN, K_OUTPROJ, K_LSTM_REC, K_LSTM_GATES, K_SDE, K_EMBED, K_UNEMBED = range(8)
 
 
 class FFDError(RuntimeError):
@@ -93,8 +95,12 @@ SIGNATURES = {
                                    C.c_uint64, _P, C.c_int, C.c_int, _P]),
     "ffd_flops_per_sample_step": (C.c_double, [_P, C.c_int]),
     "ffd_ffn_flops_per_launch": (C.c_double, [_P, C.c_int]),
-    "ffd_ffn_timing_begin": (C.c_int, [_P, C.c_int]),
-    "ffd_ffn_timing_end": (C.c_int, [_P, _F, C.POINTER(C.c_int)]),
+    "ffd_kernel_timing_begin": (C.c_int, [_P, C.c_uint32, C.c_int]),
+    "ffd_kernel_timing_end": (C.c_int, [_P]),
+    "ffd_kernel_timing_get": (C.c_int, [_P, C.c_int, _F, C.POINTER(C.c_int)]),
+    "ffd_kernel_work": (C.c_char_p, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ffd_score_forward_ts": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "ffd_cache_configure": (C.c_int, [_P, C.POINTER(CacheCfg)]),
     "ffd_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
 }

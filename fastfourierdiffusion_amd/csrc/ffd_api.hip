@@ -68,10 +68,14 @@ struct ffd_ctx {
   int temb_cap = 0;
   std::vector<float> ts_host;
   long weight_epoch = 0, temb_epoch = -1;
-  // in-situ timing of the dominant kernel (ffd_ffn_timing_*)
-  bool time_ffn = false;
+  // in-situ kernel timing (ffd_kernel_timing_*)
+  uint32_t time_mask = 0;
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
+  std::vector<int> ev_cls;     // kernel class of each used pair
   size_t ev_used = 0;
+  float tm_ms[FFD_K_COUNT] = {0};
+  int tm_n[FFD_K_COUNT] = {0};
+  float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
   // FreSca (sampler-level)
   bool fresca_on = false;
   bool crf_cap_on = false;
@@ -116,6 +120,31 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
 }
 
 static int g_bench_kernel = 0;
+
+// HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
+struct Timed {
+  ffd_ctx* ctx;
+  hipStream_t s;
+  bool on;
+  Timed(ffd_ctx* c, int cls, hipStream_t st) : ctx(c), s(st) {
+    on = ((c->time_mask >> cls) & 1u) && c->ev_used + 2 <= c->ev.size();
+    if (on) {
+      (void)hipEventRecord(c->ev[c->ev_used], s);
+      c->ev_cls.push_back(cls);
+    }
+  }
+  ~Timed() {
+    if (on) {
+      (void)hipEventRecord(ctx->ev[ctx->ev_used + 1], s);
+      ctx->ev_used += 2;
+    }
+  }
+};
+#define TIMED(cls, expr)      \
+  do {                        \
+    Timed tm__(ctx, cls, s);  \
+    HIPCHECK(expr);           \
+  } while (0)
 
 static bool d_supported(int d) {
 #define X(v) if (d == v) return true;
@@ -472,6 +501,7 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->h0, M * d))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->score, M * m.n_channels))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->temb_b, (size_t)B * d))) return rc;
   if (m.kind == FFD_MODEL_MLP) {
     if ((rc = dev_alloc(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
     if ((rc = dev_alloc(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
@@ -486,17 +516,19 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   return FFD_OK;
 }
 
-// one score evaluation; temb points at d floats on the device.
+// one score evaluation; temb points at d floats on the device (temb_stride = 0: shared by the batch) or at a
+// (B, d) table (temb_stride = d: per-sample diffusion times).
 // n_rec < 0: no cache.  Otherwise the E2-CRF mode for |recompute_tokens| = n_rec.
-static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* score_out, float* crf_out, int B,
-                        int n_rec, hipStream_t s) {
+static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int temb_stride, float* score_out,
+                        float* crf_out, int B, int n_rec, hipStream_t s) {
   const ffd_model_desc& m = ctx->desc;
   const int L = m.max_len, C = m.n_channels, d = m.d_model, M = B * L;
   if (m.kind == FFD_MODEL_MLP) {  // MLPScoreModule.forward, score_models.py:406-440
     const int io = L * C, F = m.dim_feedforward;
     // flatten "b t c -> b (t c)" is the memory layout already; time encoding is one (d,) vector per step
-    HIPCHECK(launch_dense(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, temb, nullptr, ctx->h0, B, d,
-                          io, 0, s));
+    // embedder(X) + time encoding: one (d,) vector per step (second bias), or a (B, d) table (added like a residual)
+    HIPCHECK(launch_dense(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, temb_stride ? nullptr : temb,
+                          temb_stride ? temb : nullptr, ctx->h0, B, d, io, 0, s));
     float* cur = ctx->h0;
     float* alt = ctx->h1;
     for (int i = 0; i < m.num_layers; ++i) {
@@ -514,20 +546,20 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
     return FFD_OK;
   }
   if (m.kind == FFD_MODEL_LSTM) {
-    HIPCHECK(launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb, ctx->h0, B, L,
-                          C, d, s));
+    TIMED(FFD_K_EMBED, launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb,
+                                    temb_stride, ctx->h0, B, L, C, d, s));
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];
-      HIPCHECK(launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
-      HIPCHECK(launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
+      TIMED(FFD_K_LSTM_GATES, launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
+      TIMED(FFD_K_LSTM_REC, launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
     }
-    HIPCHECK(launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C,
-                            d, s));
+    TIMED(FFD_K_UNEMBED, launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p,
+                                        score_out, M, C, d, s));
     return FFD_OK;
   }
   const int H = m.n_head, hd = d / H, F = m.dim_feedforward;
-  HIPCHECK(launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p,
-                        ctx->raw["pos_encoder.embedding.weight"].p, temb, ctx->h0, B, L, C, d, s));
+  TIMED(FFD_K_EMBED, launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p,
+                                  ctx->raw["pos_encoder.embedding.weight"].p, temb, temb_stride, ctx->h0, B, L, C, d, s));
   // mode selection, cached_transformer.py:139-220
   enum { STD, FULL, PURE, MIXED } mode = STD;
   if (n_rec >= 0) {
@@ -561,9 +593,9 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
       // element 0's workgroups also publish their recomputed K/V rows (caching.py:326-328)
       const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L) : 1;
       const float* pack = hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
-      HIPCHECK(launch_qkv_attention(cur, pack, hpw, mode == PURE, tables ? kt : nullptr,
-                                    tables ? vt : nullptr, mode == MIXED ? kt : nullptr, mode == MIXED ? vt : nullptr,
-                                    ctx->attn, B, L, d, hd, n_own, s));
+      TIMED(FFD_K_ATTN, launch_qkv_attention(cur, pack, hpw, mode == PURE, tables ? kt : nullptr,
+                                             tables ? vt : nullptr, mode == MIXED ? kt : nullptr,
+                                             mode == MIXED ? vt : nullptr, ctx->attn, B, L, d, hd, n_own, s));
     } else {
       if (!fused) HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
       HIPCHECK(launch_attention(qreg, kreg, vreg, tables ? kt : nullptr, tables ? vt : nullptr, ctx->attn, B, L, H, hd,
@@ -584,14 +616,8 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
       cur = alt;
       alt = t;
     } else {
-      HIPCHECK(launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-      const bool timed = ctx->time_ffn && ctx->ev_used + 2 <= ctx->ev.size();
-      if (timed) HIPCHECK(hipEventRecord(ctx->ev[ctx->ev_used], s));
-      HIPCHECK(launch_ffn_ln(alt, w, cur, M, d, F, s));
-      if (timed) {
-        HIPCHECK(hipEventRecord(ctx->ev[ctx->ev_used + 1], s));
-        ctx->ev_used += 2;
-      }
+      TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+      TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s));
     }
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
@@ -610,8 +636,8 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, float* 
       ctx->table_allocated = true;
     }
   }
-  HIPCHECK(launch_unembed(cur, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out, M, C, d,
-                          s));
+  TIMED(FFD_K_UNEMBED, launch_unembed(cur, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out,
+                                      M, C, d, s));
   return FFD_OK;
 }
 
@@ -638,7 +664,7 @@ int ffd_score_forward(ffd_ctx* ctx, const float* x, float t, float* score_out, i
   if ((rc = ensure_workspace(ctx, B))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = temb_single(ctx, t, s))) return rc;
-  return forward_impl(ctx, x, ctx->temb1, score_out, nullptr, B, -1, s);
+  return forward_impl(ctx, x, ctx->temb1, 0, score_out, nullptr, B, -1, s);
 }
 
 int ffd_score_forward_cached(ffd_ctx* ctx, const float* x, float t, float* score_out, float* crf_out, int B,
@@ -656,7 +682,30 @@ int ffd_score_forward_cached(ffd_ctx* ctx, const float* x, float t, float* score
   if ((rc = ensure_workspace(ctx, B))) return rc;
   hipStream_t s = (hipStream_t)stream;
   if ((rc = temb_single(ctx, t, s))) return rc;
-  return forward_impl(ctx, x, ctx->temb1, score_out, crf_out, B, n_recompute, s);
+  return forward_impl(ctx, x, ctx->temb1, 0, score_out, crf_out, B, n_recompute, s);
+}
+
+int ffd_score_forward_ts(ffd_ctx* ctx, const float* x, const float* timesteps, float* score_out, float* crf_out,
+                         int B, int n_recompute, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (!x || !timesteps || !score_out) return ctx->fail(FFD_ERR_INVALID, "null buffer");
+  if (n_recompute >= 0) {
+    if (ctx->desc.kind != FFD_MODEL_TRANSFORMER)
+      return ctx->fail(FFD_ERR_UNSUPPORTED, "caching is only defined for the transformer backbone (SURVEY Q9)");
+    if (!ctx->cache_enabled) return ctx->fail(FFD_ERR_STATE, "cache not enabled (call ffd_cache_enable)");
+    if (n_recompute > ctx->desc.max_len)
+      return ctx->fail(FFD_ERR_INVALID, "n_recompute=%d outside [0,%d]", n_recompute, ctx->desc.max_len);
+  }
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  // one time embedding per sample: dense(gamma(t_b)) (transformer.py:77-91)
+  HIPCHECK(launch_time_embed(timesteps, 0.f, B, ctx->raw["time_encoder.W"].p, ctx->raw["time_encoder.dense.weight"].p,
+                             ctx->raw["time_encoder.dense.bias"].p, ctx->temb_b, ctx->desc.d_model, s));
+  return forward_impl(ctx, x, ctx->temb_b, ctx->desc.d_model, score_out, n_recompute >= 0 ? crf_out : nullptr, B,
+                      n_recompute >= 0 ? n_recompute : -1, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -873,6 +922,14 @@ int ffd_cache_enable(ffd_ctx* ctx, const ffd_cache_cfg* cfg) {
   return ffd_cache_reset(ctx);
 }
 
+int ffd_cache_configure(ffd_ctx* ctx, const ffd_cache_cfg* cfg) {
+  if (!ctx) return FFD_ERR_INVALID;
+  if (!cfg) return ctx->fail(FFD_ERR_INVALID, "null cache config");
+  if (!ctx->cache_enabled) return ctx->fail(FFD_ERR_STATE, "cache not enabled (call ffd_cache_enable)");
+  ctx->ccfg = *cfg;
+  return FFD_OK;
+}
+
 int ffd_cache_disable(ffd_ctx* ctx) {
   if (!ctx) return FFD_ERR_INVALID;
   ctx->cache_enabled = false;
@@ -979,7 +1036,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
         }
       }
     }
-    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, ctx->score, crf_dst, B, n_rec, s))) return rc;
+    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, 0, ctx->score, crf_dst, B, n_rec, s))) return rc;
     if (crf_copy)
       HIPCHECK(hipMemcpyAsync(crf_copy, crf_dst, sizeof(float) * (size_t)m.num_layers * m.max_len * d,
                               hipMemcpyDeviceToDevice, s));
@@ -996,9 +1053,9 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
         score = ctx->score2;
       }
     }
-    HIPCHECK(launch_sde_step(x, score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
-                             sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B, m.max_len,
-                             m.n_channels, s));
+    TIMED(FFD_K_SDE, launch_sde_step(x, score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
+                                     sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B,
+                                     m.max_len, m.n_channels, s));
   }
   return FFD_OK;
 }
@@ -1023,7 +1080,7 @@ double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B) {
   return 4.0 * (double)B * m.max_len * m.d_model * m.dim_feedforward;
 }
 
-int ffd_ffn_timing_begin(ffd_ctx* ctx, int max_launches) {
+int ffd_kernel_timing_begin(ffd_ctx* ctx, uint32_t class_mask, int max_launches) {
   if (!ctx) return FFD_ERR_INVALID;
   if (max_launches < 1 || max_launches > 100000) return ctx->fail(FFD_ERR_INVALID, "max_launches=%d", max_launches);
   HIPCHECK(hipSetDevice(ctx->device));
@@ -1033,27 +1090,81 @@ int ffd_ffn_timing_begin(ffd_ctx* ctx, int max_launches) {
     ctx->ev.push_back(e);
   }
   ctx->ev_used = 0;
-  ctx->time_ffn = true;
+  ctx->ev_cls.clear();
+  ctx->time_mask = class_mask;
   return FFD_OK;
 }
 
-int ffd_ffn_timing_end(ffd_ctx* ctx, float* avg_ms_out, int* launches_out) {
+int ffd_kernel_timing_end(ffd_ctx* ctx) {
   if (!ctx) return FFD_ERR_INVALID;
-  ctx->time_ffn = false;
-  if (!avg_ms_out || !launches_out) return ctx->fail(FFD_ERR_INVALID, "null output");
+  ctx->time_mask = 0;
   HIPCHECK(hipSetDevice(ctx->device));
-  double tot = 0.0;
+  double tot[FFD_K_COUNT] = {0};
+  for (int c = 0; c < FFD_K_COUNT; ++c) ctx->tm_n[c] = 0;
   const size_t n = ctx->ev_used / 2;
   for (size_t i = 0; i < n; ++i) {
     HIPCHECK(hipEventSynchronize(ctx->ev[2 * i + 1]));
     float ms = 0.f;
     HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
-    tot += ms;
+    const int c = ctx->ev_cls[i];
+    tot[c] += ms;
+    ctx->tm_n[c]++;
   }
-  *avg_ms_out = n ? (float)(tot / n) : 0.f;
-  *launches_out = (int)n;
+  for (int c = 0; c < FFD_K_COUNT; ++c) ctx->tm_ms[c] = ctx->tm_n[c] ? (float)(tot[c] / ctx->tm_n[c]) : 0.f;
   ctx->ev_used = 0;
+  ctx->ev_cls.clear();
   return FFD_OK;
+}
+
+int ffd_kernel_timing_get(const ffd_ctx* ctx, int kernel_class, float* avg_ms_out, int* launches_out) {
+  if (!ctx || kernel_class < 0 || kernel_class >= FFD_K_COUNT || !avg_ms_out || !launches_out) return FFD_ERR_INVALID;
+  *avg_ms_out = ctx->tm_ms[kernel_class];
+  *launches_out = ctx->tm_n[kernel_class];
+  return FFD_OK;
+}
+
+const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cache_hit, double* flops_out,
+                            double* bytes_out) {
+  if (!ctx || B < 1) return nullptr;
+  const ffd_model_desc& m = ctx->desc;
+  const double L = m.max_len, d = m.d_model, C = m.n_channels, F = m.dim_feedforward, M = (double)B * L;
+  const bool tr = m.kind == FFD_MODEL_TRANSFORMER, ls = m.kind == FFD_MODEL_LSTM;
+  double fl = 0.0, by = 0.0;
+  const char* name = nullptr;
+  switch (kernel_class) {
+    case FFD_K_FFN:  // 4 d F FLOP per row; x in, y out, both weight matrices once
+      if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
+      break;
+    case FFD_K_ATTN:  // in-projection (Q only on a pure-cache step) + QK^T + PV; x in, attention output out
+      if (tr) {
+        name = "k_qkv_attention";
+        fl = M * (2.0 * d * (cache_hit ? d : 3.0 * d) + 4.0 * L * d);
+        by = 4.0 * (2.0 * M * d + 3.0 * d * d + (cache_hit ? 2.0 * L * d : 0.0));
+      }
+      break;
+    case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
+      if (tr) name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
+      break;
+    case FFD_K_LSTM_REC:  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out
+      if (ls) name = "k_lstm_layer", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * 4.0 * d + 2.0 * M * d + 4.0 * d * d);
+      break;
+    case FFD_K_LSTM_GATES:
+      if (ls) name = "k_linear_rm", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * d + M * 4.0 * d + 4.0 * d * d);
+      break;
+    case FFD_K_SDE:  // x, score in; x out (noise generated on chip): 12 B per element
+      name = "k_sde_step", by = 12.0 * M * C;
+      break;
+    case FFD_K_EMBED:
+      if (m.kind != FFD_MODEL_MLP) name = "k_embed", fl = 2.0 * M * C * d, by = 4.0 * M * (C + d);
+      break;
+    case FFD_K_UNEMBED:
+      if (m.kind != FFD_MODEL_MLP) name = "k_unembed", fl = 2.0 * M * C * d, by = 4.0 * M * (C + d);
+      break;
+    default: break;
+  }
+  if (flops_out) *flops_out = fl;
+  if (bytes_out) *bytes_out = by;
+  return name;
 }
 
 int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {

@@ -141,8 +141,8 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 // embed: h[row][j] = be[j] + sum_c X[row][c] We[j][c] (+ pos[l][j]) + temb[j]
 // ---------------------------------------------------------------------------
 __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ We, const float* __restrict__ be,
-                        const float* __restrict__ pos, const float* __restrict__ temb, float* __restrict__ h,
-                        unsigned total4, int L, int C, int D) {
+                        const float* __restrict__ pos, const float* __restrict__ temb, int temb_stride,
+                        float* __restrict__ h, unsigned total4, int L, int C, int D) {
   // The (D x C) embedder weight is staged transposed in LDS ([c][j]), so the C weights of an output float4 are C
   // aligned 16-byte LDS reads instead of 4 C scattered global loads.  One float4 of h per thread and iteration
   // (D % 4 == 0); 32-bit index math only; same operation order as before the staging.
@@ -155,7 +155,8 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
   for (unsigned i4 = blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += gridDim.x * blockDim.x) {
     const unsigned row = (4u * i4) / (unsigned)D;
     const int j = (int)(4u * i4 - row * (unsigned)D);
-    const int l = (int)(row % (unsigned)L);
+    const unsigned bidx = row / (unsigned)L;
+    const int l = (int)(row - bidx * (unsigned)L);
     const float* x = X + (size_t)row * C;
     float4 v = float4{be[j], be[j + 1], be[j + 2], be[j + 3]};
     for (int c = 0; c < C; ++c) {
@@ -167,19 +168,19 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
       const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)l * D + j);
       v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
     }
-    const float4 t = *reinterpret_cast<const float4*>(temb + j);
+    const float4 t = *reinterpret_cast<const float4*>(temb + (size_t)bidx * temb_stride + j);
     reinterpret_cast<float4*>(h)[i4] = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
   }
 }
 
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
-                        float* h, int B, int L, int C, int D, hipStream_t s) {
+                        int temb_stride, float* h, int B, int L, int C, int D, hipStream_t s) {
   const unsigned total4 = (unsigned)((size_t)B * L * D / 4);
   unsigned blocks = (total4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;  // grid-stride: the weight staging is amortised over >= a few rows per thread
   const size_t lds = (size_t)C * D * sizeof(float);
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), lds, s, X, We, be, pos, temb, h, total4, L, C, D);
+  hipLaunchKernelGGL(k_embed, dim3(blocks), dim3(256), lds, s, X, We, be, pos, temb, temb_stride, h, total4, L, C, D);
   return hipGetLastError();
 }
 
@@ -344,7 +345,7 @@ __global__ void k_sde_step(float* __restrict__ x, const float* __restrict__ scor
     load_normals(z, i0, n, seed, elem_offset, step, zz);
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
-      const int l = (int)(((unsigned)i / (unsigned)C) % (unsigned)L);
+      const int l = (int)((i / (size_t)C) % (size_t)L);
       float g = __fmul_rn(p.cs, G[l]);
       float g2 = __fmul_rn(g, g);
       float xi = x[i];
@@ -377,7 +378,7 @@ __global__ void k_prior(float* __restrict__ x, const float* __restrict__ z, cons
     load_normals(z, i0, n, seed, elem_offset, 0xFFFFFFFFu, zz);
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
-      const int l = (int)(((unsigned)i / (unsigned)C) % (unsigned)L);
+      const int l = (int)((i / (size_t)C) % (size_t)L);
       float v0 = __fmul_rn(G[l], zz[j]);
       x[i] = (scale == 1.0f) ? v0 : __fmul_rn(scale, v0);
     }

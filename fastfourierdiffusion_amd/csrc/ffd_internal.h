@@ -82,9 +82,9 @@ hipError_t launch_add_table(const float* x, const float* rowtab, const float* ba
 // (ts == nullptr: a single embedding of the immediate t_imm)
 hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W, const float* dense_w,
                              const float* dense_b, float* temb, int D, hipStream_t s);
-// h[b,l,:] = X[b,l,:] We^T + be (+ pos[l,:]) + temb[:]
+// h[b,l,:] = X[b,l,:] We^T + be (+ pos[l,:]) + temb[b * temb_stride + :]   (temb_stride 0: one embedding for the batch)
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
-                        float* h, int B, int L, int C, int D, hipStream_t s);
+                        int temb_stride, float* h, int B, int L, int C, int D, hipStream_t s);
 // score[b,l,c] = h[b,l,:] . Wu[c,:] + bu[c]
 hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, float* score, int M, int C, int D,
                           hipStream_t s);

@@ -186,15 +186,16 @@ class ScoreModule(nn.Module):
         assert timesteps is not None and timesteps.size(0) == len(batch)
         X = N.require_gpu_tensor(X, "batch.X")
         ctx = self._ctx()
-        # one diffusion time per call (sampler.py:59-60 asserts min == max)
-        t = float(timesteps[0])
+        # per-sample diffusion times, as time_encoder(X, timesteps) evaluates them (score_models.py:102;
+        # tests/test_score_models.py:70 passes mixed timesteps); they stay on the device -- no host sync
+        ts = timesteps.to(device=X.device, dtype=torch.float32).contiguous()
         B = X.shape[0]
         score = torch.empty_like(X)
         stream = N.current_stream_ptr(X.device)
         cached = self.use_cache and recompute_tokens is not None and self.cached_backbone is not None
         if not cached:
-            N.check(ctx.lib.ffd_score_forward(ctx.handle, X.data_ptr(), t, score.data_ptr(), B, stream), ctx.handle,
-                    "ffd_score_forward")
+            N.check(ctx.lib.ffd_score_forward_ts(ctx.handle, X.data_ptr(), ts.data_ptr(), score.data_ptr(), None, B, -1,
+                                                 stream), ctx.handle, "ffd_score_forward_ts")
             return (score, None) if return_crf else score
         n = len(recompute_tokens)
         if set(recompute_tokens) != set(range(n)):
@@ -203,9 +204,9 @@ class ScoreModule(nn.Module):
                 "produces (caching.py:131-181)")
         crf = torch.empty((self.num_layers, self.max_len, self.d_model), device=X.device, dtype=torch.float32) \
             if return_crf else None
-        N.check(ctx.lib.ffd_score_forward_cached(ctx.handle, X.data_ptr(), t, score.data_ptr(),
-                                                 crf.data_ptr() if crf is not None else None, B, n, stream),
-                ctx.handle, "ffd_score_forward_cached")
+        N.check(ctx.lib.ffd_score_forward_ts(ctx.handle, X.data_ptr(), ts.data_ptr(), score.data_ptr(),
+                                             crf.data_ptr() if crf is not None else None, B, n, stream),
+                ctx.handle, "ffd_score_forward_ts")
         return (score, crf) if return_crf else score
 
     # ------------------------------------------------------------------
@@ -236,6 +237,13 @@ class ScoreModule(nn.Module):
         cfg = N.CacheCfg(int(fc.K), int(fc.R)) if fc is not None else N.CacheCfg(5, 10)
         N.check(self._native.lib.ffd_cache_enable(self._native.handle, C.byref(cfg)), self._native.handle,
                 "ffd_cache_enable")
+
+    def _native_cache_configure(self, cache: E2CRFCache) -> None:
+        """Gate parameters of the sampler's *current* cache (the tables stay bound to the first one, Q5)."""
+        if self._native is not None:
+            cfg = N.CacheCfg(int(cache.K), int(cache.R))
+            N.check(self._native.lib.ffd_cache_configure(self._native.handle, C.byref(cfg)), self._native.handle,
+                    "ffd_cache_configure")
 
     def _native_cache_reset(self) -> None:
         if self._native is not None:

@@ -140,6 +140,8 @@ class DiffusionSampler:
                     model.cache.reset()  # sampler.py:151-153
                     global_step = 0
                 use_cache = int(self.use_cache and model.cache is not None)
+                if use_cache:  # the gate reads K, R of the current cache object (sampler.py:179-200)
+                    model._native_cache_configure(model.cache)
                 cap = self._crf_capture_begin(ctx, device) if use_cache else None
                 done = 0
                 while done < num_diffusion_steps:

@@ -32,3 +32,16 @@ def reduce_max_seconds(seconds: float, device: Optional[object]) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_seconds(seconds: float, device: Optional[object]) -> list:
+    """Every rank's wall-clock interval, in rank order (a one-element list when not distributed)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(seconds)]
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]

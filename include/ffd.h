@@ -136,6 +136,14 @@ int ffd_score_forward(ffd_ctx* ctx, const float* x, float t, float* score_out, i
 int ffd_score_forward_cached(ffd_ctx* ctx, const float* x, float t, float* score_out, float* crf_out,
                              int B, int n_recompute, void* stream);
 
+/* The same two forwards with PER-SAMPLE diffusion times: the reference evaluates
+ * time_encoder(X, timesteps) per sample (score_models.py:102, transformer.py:77-91) and its own
+ * unit test calls forward with mixed timesteps (tests/test_score_models.py:70).  `timesteps` is
+ * a (B) fp32 device array; no host synchronisation.  n_recompute < 0: no cache (ffd_score_forward);
+ * otherwise the cached forward for |recompute_tokens| = n_recompute (crf_out may be NULL). */
+int ffd_score_forward_ts(ffd_ctx* ctx, const float* x, const float* timesteps, float* score_out, float* crf_out,
+                         int B, int n_recompute, void* stream);
+
 /* Scheduler hyper-parameters for the context-free scheduler operators below
  * (VPScheduler / VEScheduler constructor arguments, sde.py:91-97, 169-175). */
 typedef struct {
@@ -247,6 +255,11 @@ int ffd_cache_crf_capture(ffd_ctx* ctx, const ffd_crf_capture_cfg* cfg);
 int ffd_cache_enable(ffd_ctx* ctx, const ffd_cache_cfg* cfg);
 int ffd_cache_disable(ffd_ctx* ctx);
 int ffd_cache_reset(ffd_ctx* ctx);
+/* K and R the gate of ffd_sample_batch uses from now on, WITHOUT touching tables or counters: the
+ * reference evaluates determine_recompute_set on the sampler's current score_model.cache
+ * (sampler.py:179-200), which a later enable_caching(**kwargs) replaces while the layers stay bound to
+ * the first cache's tables (score_models.py:232). */
+int ffd_cache_configure(ffd_ctx* ctx, const ffd_cache_cfg* cfg);
 int ffd_cache_stats_get(const ffd_ctx* ctx, ffd_cache_stats* out);
 /* Copy the (NL,H,L,hd) K and V tables (caching.py:88-91; zeros until step 0 ran) into
  * caller-owned device buffers; stream ordered.  Requires ffd_cache_enable. */
@@ -287,12 +300,30 @@ int ffd_tune(const char* key, int value);
  * the fused FFN kernel per launch at batch B. */
 double ffd_flops_per_sample_step(const ffd_ctx* ctx, int cache_hit);
 double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B);
-/* In-situ timing of the dominant kernel (fused FFN + LN2): between _begin and _end every
- * k_ffn_ln launch issued by forward / sample calls on this context is bracketed by a HIP
- * event pair on the launch stream (up to max_launches); _end synchronises and returns the
- * mean duration.  For bench.py's roofline; adds two event records per timed launch. */
-int ffd_ffn_timing_begin(ffd_ctx* ctx, int max_launches);
-int ffd_ffn_timing_end(ffd_ctx* ctx, float* avg_ms_out, int* launches_out);
+/* Kernel classes of the sampling path, for in-situ timing and roofline accounting. */
+enum {
+  FFD_K_FFN = 0,         /* k_ffn_ln: linear1 + relu + linear2 + residual + LayerNorm2 */
+  FFD_K_ATTN = 1,        /* k_qkv_attention*: in-projection + attention (or the two-kernel fallback) */
+  FFD_K_OUTPROJ = 2,     /* k_linear_res_ln: out-projection + residual + LayerNorm1 */
+  FFD_K_LSTM_REC = 3,    /* k_lstm_*: the L-step recurrence of one residual LSTM layer */
+  FFD_K_LSTM_GATES = 4,  /* k_linear_rm: input-gate GEMM of one LSTM layer */
+  FFD_K_SDE = 5,         /* k_sde_step (or the fused unembed + SDE step) */
+  FFD_K_EMBED = 6,
+  FFD_K_UNEMBED = 7,
+  FFD_K_COUNT = 8
+};
+/* In-situ timing: between _begin and _end every launch of a kernel whose class bit is set in
+ * `class_mask`, issued by forward / sample calls on this context, is bracketed by a HIP event pair
+ * on the launch stream (up to max_launches pairs in total); _end synchronises; _get returns the mean
+ * duration and launch count of one class.  For bench.py's roofline lines. */
+int ffd_kernel_timing_begin(ffd_ctx* ctx, uint32_t class_mask, int max_launches);
+int ffd_kernel_timing_end(ffd_ctx* ctx);
+int ffd_kernel_timing_get(const ffd_ctx* ctx, int kernel_class, float* avg_ms_out, int* launches_out);
+/* Algorithmic work of ONE launch of a kernel class at batch B (SURVEY 8(d) figures: FLOPs for the
+ * MFMA-bound classes, HBM bytes for all); cache_hit = 1 for a pure-cache step.  Returns the kernel's
+ * name (static string) or NULL for a class this model does not launch. */
+const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cache_hit, double* flops_out,
+                            double* bytes_out);
 /* Time `iters` launches of the dominant kernel (fused FFN+LN2 of layer 0) at batch B
  * on `stream` with HIP events; returns average milliseconds per launch in *ms_out.
  * Synchronous (benchmark helper only). */

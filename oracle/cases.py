@@ -172,3 +172,28 @@ MASK_CASES = [
     ("m2_energy", (10, 14), 0.4, "energy", 103),
 ]
 ANALYZE_CASES = [("an_ecg", 1, 187, 1, 111, 0.5), ("an_b_eq_nf", 51, 100, 3, 112, 0.3)]  # (name, B, L, C, seed, ratio)
+
+
+# ---- round 2 (g12) -----------------------------------------------------------------------------------
+# ScoreModule.forward with PER-SAMPLE timesteps (time_encoder(X, timesteps), score_models.py:102); "int" = the
+# reference's own unit test draws integer timesteps with torch.randint(0, n_diffusion_steps) (tests/test_score_models.py:70)
+MIXED_T_CASES = [
+    dict(name="mt_refunit", **_REFUNIT, sde="vp", sde_kwargs=VP, fourier=True, B=5, wseed=47, xseed=121, t=[3, 0, 7, 9, 1], int_t=True),
+    dict(name="mt_refunit_lstm", **_REFUNIT_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=5, wseed=48, xseed=122, t=[3, 0, 7, 9, 1], int_t=True),
+    dict(name="mt_small", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=4, wseed=42, xseed=123, t=[1.0, 0.61, 0.25, 1e-5], int_t=False,
+         recompute=[list(range(20)), [], list(range(10))]),
+    dict(name="mt_ecg", **_ECG, sde="vp", sde_kwargs=VP, fourier=True, B=3, wseed=42, xseed=124, t=[0.9, 0.5, 0.1], int_t=False),
+    dict(name="mt_nasa_lstm", **_NASA_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=2, wseed=45, xseed=125, t=[0.8, 0.2], int_t=False),
+]
+# BASELINE configs[4] shape, short cached trajectory
+SYN_TRAJ_CASES = [
+    dict(name="traj_syn_cache", **_SYN, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2, N=8, use_cache=True,
+         cache_kwargs={}, wseed=44, zseed=131),
+]
+# two samplers on ONE model with different gate parameters (cmd/benchmark_cache.py:274-311 re-uses the model like this):
+# the second sampler must run ITS cache's K / R although the layers stay bound to the first cache (Q5)
+TWO_SAMPLER_CASE = dict(name="two_samplers", **_SMALL, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=4, N=104,
+                        first_kwargs={}, second_kwargs={"K": 10, "R": 100}, wseed=42, zseed1=132, zseed2=133)
+# cmd/sample.py:107-113 (X * std + mean, then idft) and its ingest twin datamodules.py:42-62 ((dft(X) - mean) / std).
+# (L, C, B, seed)
+AFFINE_FFT_CASES = [(187, 1, 4, 141), (251, 4, 3, 142), (100, 3, 2, 143), (512, 8, 2, 144)]

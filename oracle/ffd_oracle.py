@@ -139,6 +139,18 @@ def idft(xt: Tensor) -> Tensor:
     return torch.from_numpy(out.astype(np.float32))
 
 
+def unstandardize_idft(x: Tensor, feature_mean: Tensor, feature_std: Tensor) -> Tensor:
+    """cmd/sample.py:107-113: ``X = X * feature_std + feature_mean`` (fp32 tensor ops, mean / std of shape (L, C)
+    broadcast over the batch), then ``X = idft(X)``."""
+    return idft(x * feature_std + feature_mean)
+
+
+def dft_standardize(x: Tensor, feature_mean: Tensor, feature_std: Tensor) -> Tensor:
+    """DiffusionDataset, datamodules.py:42-43,61-62: ``X = dft(X)`` at construction, then
+    ``(X - feature_mean) / feature_std`` per item (fp32)."""
+    return (dft(x) - feature_mean) / feature_std
+
+
 # --------------------------------------------------------------------------
 # F3 : FreSca spectral scaling of the score   (src/fdiff/utils/fresca.py)
 # --------------------------------------------------------------------------

@@ -167,10 +167,67 @@ def gen_extra_traj(ns) -> None:
     np.savez_compressed(os.path.join(OUT, "g11_extra_traj.npz"), **g)
 
 
+def gen_round2(ns) -> None:
+    """G12: per-sample timesteps, a config-5-shaped cached trajectory, two samplers on one model with different
+    gate parameters, and the (un)standardise + (i)dft wrappers of cmd/sample.py / datamodules.py."""
+    g = {}
+    for c in cases.MIXED_T_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C = c["B"], c["L"], c["C"]
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+        t = torch.tensor(c["t"], dtype=torch.int64 if c["int_t"] else torch.float32)
+        with torch.no_grad():
+            g[c["name"] + "_score"] = m(ns.DiffusableBatch(X=x, y=None, timesteps=t)).numpy()
+            if c.get("recompute"):
+                m.enable_caching()
+                m.eval()
+                m.cache.reset()
+                for j, rec in enumerate(c["recompute"]):
+                    xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"] + 100 + j)))
+                    sc, crf = m(ns.DiffusableBatch(X=xj, y=None, timesteps=t), recompute_tokens=set(rec), step=j,
+                                return_crf=True)
+                    g[f"{c['name']}_cseq{j}_score"] = sc.numpy()
+                    g[f"{c['name']}_cseq{j}_crf"] = crf.numpy().copy()
+                m.disable_caching()
+        print(c["name"])
+    for c in cases.SYN_TRAJ_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+        stream = synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), c["zseed"])
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=True, cache_kwargs=dict(c["cache_kwargs"]))
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        g[c["name"]] = out.numpy()
+        g[c["name"] + "_ts"] = sch.timesteps.numpy().copy()
+        print(c["name"], out.shape, float(out.abs().max()))
+    c = cases.TWO_SAMPLER_CASE
+    m, sch = make_model(ns, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    for tag, kw, zs in (("first", c["first_kwargs"], c["zseed1"]), ("second", c["second_kwargs"], c["zseed2"])):
+        stream = synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), zs)
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=True, cache_kwargs=dict(kw))
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        g[f"{c['name']}_{tag}"] = out.numpy()
+        st = m.cache.get_cache_stats()
+        g[f"{c['name']}_{tag}_stats"] = np.array([st["recompute_count"], st["cache_hit_count"]], dtype=np.int64)
+    g[c["name"] + "_ts"] = sch.timesteps.numpy().copy()
+    print(c["name"])
+    for (L, C, B, seed) in cases.AFFINE_FFT_CASES:
+        x, mean, std = (torch.from_numpy(a) for a in synthetic.noise_stream((B, L, C), 3, seed))
+        mean, std = mean[0], std[0].abs() + 0.5
+        g[f"unstd_idft_L{L}_C{C}"] = ns.idft(x * std + mean).numpy()   # cmd/sample.py:107-113
+        g[f"dft_std_L{L}_C{C}"] = ((ns.dft(x) - mean) / std).numpy()    # datamodules.py:42-43,61-62
+    np.savez_compressed(os.path.join(OUT, "g12_round2.npz"), **g)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
+    if "--only-round2" in sys.argv:  # just G12
+        gen_round2(ns)
+        return
     if "--only-freqca" in sys.argv:  # regenerate just G10 (the 1000-step trajectories take minutes)
         gen_freqca(ns)
         return
@@ -302,6 +359,7 @@ def main() -> None:
 
     gen_freqca(ns)
     gen_extra_traj(ns)
+    gen_round2(ns)
 
     with open(os.path.join(OUT, "META.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from the unmodified reference at /root/reference\n")

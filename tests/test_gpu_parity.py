@@ -797,3 +797,203 @@ def test_compute_event_intensity_vs_reference_formula(ffd):
     got = cache.compute_event_intensity(b.cuda(), 4)
     assert abs(got - want) < 2e-6 * max(1.0, want)
     assert cache.compute_event_intensity((a + 100.0).cuda(), 5) == 1.0  # clipped
+
+
+# ------------------------------------------------------------- round 2 (g12) ----
+def _pin_grid(sch, ts_np, N):
+    """Golden trajectories were generated on the grid stored next to them (torch.linspace's last ulp depends on the
+    host's vector width): make set_timesteps(N) install exactly that grid."""
+    ts_golden = torch.from_numpy(np.asarray(ts_np).copy())
+    orig = sch.set_timesteps
+
+    def pinned(n):
+        orig(n)
+        assert n == N
+        sch.timesteps = ts_golden
+        sch.step_size = ts_golden[0] - ts_golden[1]
+
+    sch.set_timesteps = pinned
+
+
+@pytest.mark.parametrize("c", cases.MIXED_T_CASES, ids=lambda c: c["name"])
+def test_mixed_timesteps_golden(ffd, golden, c):
+    """ScoreModule.forward evaluates the time encoder PER SAMPLE (score_models.py:102); the reference's own unit
+    test passes torch.randint timesteps (tests/test_score_models.py:70).  Golden from the reference (g12)."""
+    from fastfourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+
+    g = golden["g12_round2"]
+    m, _ = make_model(ffd, c)
+    B, L, C = c["B"], c["L"], c["C"]
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"]))).cuda()
+    t = torch.tensor(c["t"], dtype=torch.int64 if c["int_t"] else torch.float32).cuda()
+    sc = m(DiffusableBatch(X=x, y=None, timesteps=t))
+    assert rel_err(sc.cpu(), g[c["name"] + "_score"]) < TOL_SCORE
+    # each sample equals its own uniform-time evaluation (the time embedding is indexed by sample, nothing else is)
+    for b in (0, B - 1):
+        one = m(batch_of(x[b:b + 1].contiguous(), float(c["t"][b])))
+        assert rel_err(one.cpu(), sc[b:b + 1].cpu()) < 2e-6
+    if c.get("recompute"):
+        m.enable_caching()
+        m.cache.reset()
+        for j, rec in enumerate(c["recompute"]):
+            xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"] + 100 + j))).cuda()
+            sc, crf = m(DiffusableBatch(X=xj, y=None, timesteps=t), recompute_tokens=set(rec), step=j, return_crf=True)
+            assert rel_err(sc.cpu(), g[f"{c['name']}_cseq{j}_score"]) < TOL_SCORE, j
+            assert rel_err(crf.cpu(), g[f"{c['name']}_cseq{j}_crf"]) < TOL_SCORE, j
+        m.disable_caching()
+
+
+def test_scalar_and_per_sample_time_entry_points_agree(ffd):
+    """ffd_score_forward / ffd_score_forward_cached (one t for the batch) and ffd_score_forward_ts (device array of
+    equal t) run the same kernels on the same embedding values: bit-identical scores, tables and CRF."""
+    import ctypes as C
+
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "small")
+    m, _ = make_model(ffd, c)
+    m.enable_caching()
+    ctx = m._ctx()
+    B, L, Cn = 3, c["L"], c["C"]
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, Cn), 1, 5))).cuda()
+    ts = torch.full((B,), 0.37, device="cuda")
+    s = N.current_stream_ptr(x.device)
+    a, b = torch.empty_like(x), torch.empty_like(x)
+    N.check(ctx.lib.ffd_score_forward(ctx.handle, x.data_ptr(), 0.37, a.data_ptr(), B, s), ctx.handle, "fwd")
+    N.check(ctx.lib.ffd_score_forward_ts(ctx.handle, x.data_ptr(), ts.data_ptr(), b.data_ptr(), None, B, -1, s), ctx.handle, "fwd_ts")
+    assert torch.equal(a, b)
+    crf_a = torch.empty(c["NL"], L, c["d"], device="cuda")
+    crf_b = torch.empty_like(crf_a)
+    for n_rec in (L, 0, 10):
+        N.check(ctx.lib.ffd_score_forward_cached(ctx.handle, x.data_ptr(), 0.37, a.data_ptr(), crf_a.data_ptr(), B, n_rec, s),
+                ctx.handle, "cached")
+        ka, va = m.cache_tables()
+        N.check(ctx.lib.ffd_score_forward_ts(ctx.handle, x.data_ptr(), ts.data_ptr(), b.data_ptr(), crf_b.data_ptr(), B, n_rec, s),
+                ctx.handle, "cached_ts")
+        kb, vb = m.cache_tables()
+        assert torch.equal(a, b) and torch.equal(crf_a, crf_b) and torch.equal(ka, kb) and torch.equal(va, vb)
+    # a cached forward without ffd_cache_enable, and a bad recompute count, fail loudly
+    m.disable_caching()
+    with pytest.raises(AssertionError):
+        N.check(ctx.lib.ffd_score_forward_ts(ctx.handle, x.data_ptr(), ts.data_ptr(), b.data_ptr(), None, B, L + 1, s),
+                ctx.handle, "bad n_rec")
+
+
+@pytest.mark.parametrize("c", cases.SYN_TRAJ_CASES, ids=lambda c: c["name"])
+def test_syn_traj_golden(ffd, golden, c):
+    """BASELINE configs[4] shape (L=512, C=8), cached trajectory pinned against the reference."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    g = golden["g12_round2"]
+    m, sch = make_model(ffd, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    _pin_grid(sch, g[c["name"] + "_ts"], N)
+    sampler = DiffusionSampler(m, B, use_cache=True, cache_kwargs=dict(c["cache_kwargs"]))
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), c["zseed"]))
+    out = sampler.sample(c["num_samples"], N)
+    assert rel_err(out, g[c["name"]]) < TOL_TRAJ
+
+
+def test_two_samplers_one_model_golden(ffd, golden):
+    """cmd/benchmark_cache.py:274-311 builds sampler after sampler on ONE model with different cache kwargs.  The
+    gate must follow the current sampler's cache (K, R) although the tables stay bound to the first (Q5)."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    c = cases.TWO_SAMPLER_CASE
+    g = golden["g12_round2"]
+    m, sch = make_model(ffd, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    _pin_grid(sch, g[c["name"] + "_ts"], N)
+    for tag, kw, zs in (("first", c["first_kwargs"], c["zseed1"]), ("second", c["second_kwargs"], c["zseed2"])):
+        sampler = DiffusionSampler(m, B, use_cache=True, cache_kwargs=dict(kw))
+        sampler.inject_noise(synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), zs))
+        out = sampler.sample(c["num_samples"], N)
+        assert rel_err(out, g[f"{c['name']}_{tag}"]) < TOL_TRAJ, tag
+        st = m.cache.get_cache_stats()
+        np.testing.assert_array_equal([st["recompute_count"], st["cache_hit_count"]], g[f"{c['name']}_{tag}_stats"])
+    # the R=100 refresh really ran in the second sampling: with the first sampler's gate (R=10 -> interval 500) the
+    # same noise gives a different trajectory
+    s3 = DiffusionSampler(m, B, use_cache=True, cache_kwargs=dict(c["first_kwargs"]))
+    s3.inject_noise(synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), c["zseed2"]))
+    assert rel_err(s3.sample(c["num_samples"], N), g[f"{c['name']}_second"]) > 1e-4
+
+
+def test_torch_rng_draw_order(ffd):
+    """rng="torch" (the default) consumes torch's generators where the reference does (sampler.py:217-228 ->
+    sde.py:79-87: one CPU torch.randn per batch for the prior; sde.py:241/160: one device randn_like per step), so a
+    seeded run equals the injected-noise run fed with the same draws.  PARITY UNPINNED against the reference itself:
+    its CPU run consumes the CPU generator for the steps, which no device run can reproduce."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    c = next(c for c in cases.TRAJ_CASES if c["name"] == "traj_small_vp")
+    m, sch = make_model(ffd, c)
+    B, L, C, N = 3, c["L"], c["C"], 6
+    torch.manual_seed(123)
+    a = DiffusionSampler(m, B, z_chunk_steps=4).sample(2 * B, N)
+    torch.manual_seed(123)
+    draws = []
+    like = torch.empty(B, L, C, device="cuda")
+    for _ in range(2):
+        draws.append(torch.randn(B, L, C).numpy())
+        draws += [torch.randn_like(like).cpu().numpy() for _ in range(N)]
+    s = DiffusionSampler(m, B)
+    s.inject_noise(iter(draws))
+    b = s.sample(2 * B, N)
+    assert torch.equal(a, b)
+
+
+def test_cache_benchmark_grid_keys(ffd):
+    """run_cache_benchmark = the body of cmd/benchmark_cache.py:159-422: baseline, default cache, cache + FreSca and the
+    K / R / tau_0 / freq_decomp_interval / FreSca-h grids on one model, rows keyed like the reference's table."""
+    from fastfourierdiffusion_amd.benchmark import ABLATION_GRID, run_cache_benchmark
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "small")
+    m, _ = make_model(ffd, c)
+    rows = run_cache_benchmark(m, num_samples=2, num_diffusion_steps=12)
+    keys = {"Config", "Parameter", "Value", "Time (s)", "Speedup", "Time per Sample (s)", "Time per Step (s)",
+            "Cache Hit Ratio", "Cache Ratio", "Freq Decomp Count"}
+    assert all(set(r) == keys for r in rows)
+    assert [r["Config"] for r in rows[:3]] == ["No Cache", "E2-CRF (default)", "E2-CRF + FreSca"]
+    assert [r["Config"] for r in rows[3:11]] == ["K=0", "K=3", "K=5", "K=10", "R=5", "R=10", "R=20", "R=50"]
+    assert len(rows) == 3 + sum(len(v) for *_, v in ABLATION_GRID)
+    assert rows[0]["Speedup"] == 1.0 and all(r["Time (s)"] > 0 for r in rows)
+    # only the first cached run's object is bound to the layers (Q5): later configurations read zero hits, as in
+    # the reference's recorded ablation ("Hit: 0.0 %", notebooks/ablation_cache_test.ipynb:353-484)
+    assert rows[1]["Cache Hit Ratio"] > 0.9 and all(r["Cache Hit Ratio"] == 0.0 for r in rows[2:])
+    m.disable_caching()
+
+
+def test_kernel_timing_and_work_accounting(ffd):
+    """ffd_kernel_timing_*: every launch of the selected classes is bracketed by a HIP event pair on the launch
+    stream; ffd_kernel_work returns the SURVEY 8(d) figures bench.py's roofline lines are computed from."""
+    import ctypes as C
+
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, sch = make_model(ffd, c)
+    ctx = m._ctx()
+    B, L, Cn, NL, d, F = 4, c["L"], c["C"], c["NL"], c["d"], 2048
+    x = torch.randn(B, L, Cn, device="cuda")
+    sch.set_timesteps(50)
+    ts_c = (C.c_float * 50)(*sch.timesteps.tolist())
+    s = N.current_stream_ptr(x.device)
+    N.check(ctx.lib.ffd_kernel_timing_begin(ctx.handle, 0xFF, 3 * (3 * NL + 3)), ctx.handle, "begin")
+    N.check(ctx.lib.ffd_sample_batch(ctx.handle, x.data_ptr(), B, ts_c, 50, float(sch.step_size), 0, 3, 1, 0, None, 0, 0, s),
+            ctx.handle, "sample")
+    N.check(ctx.lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "end")
+    counts = {}
+    for cls in range(8):
+        ms, n = C.c_float(), C.c_int()
+        N.check(ctx.lib.ffd_kernel_timing_get(ctx.handle, cls, C.byref(ms), C.byref(n)), ctx.handle, "get")
+        counts[cls] = n.value
+        assert (ms.value > 0) == (n.value > 0)
+    assert counts[N.K_FFN] == counts[N.K_ATTN] == counts[N.K_OUTPROJ] == 3 * NL
+    assert counts[N.K_EMBED] == 3 and counts[N.K_LSTM_REC] == 0
+    assert counts[N.K_SDE] == 3  # the unembed may be fused into it
+    fl, by = C.c_double(), C.c_double()
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_ln"
+    assert fl.value == 4.0 * 512 * L * d * F  # 56.47 GFLOP at the ECG bench shape
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)) is not None
+    assert by.value == 12.0 * 512 * L * Cn
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) is None

@@ -231,15 +231,16 @@ _WORKER = r"""
 import os, sys, json
 sys.path.insert(0, {root!r})
 import torch, torch.distributed as dist
-from fastfourierdiffusion_amd.sharding import shard_range, reduce_max_seconds
+from fastfourierdiffusion_amd.sharding import shard_range, reduce_max_seconds, gather_seconds
 dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
 rank = dist.get_rank()
 off, cnt = shard_range(1001, 2, rank)
 t = reduce_max_seconds(0.5 + rank, None)
+per_rank = gather_seconds(0.5 + rank, None)
 gathered = [None, None]
 dist.all_gather_object(gathered, (off, cnt))
 if rank == 0:
-    print(json.dumps({{"ranges": gathered, "tmax": t}}))
+    print(json.dumps({{"ranges": gathered, "tmax": t, "per_rank": per_rank}}))
 dist.destroy_process_group()
 """
 
@@ -263,7 +264,61 @@ def test_shard_plan_two_ranks_gloo(tmp_path):
     import json
 
     res = json.loads(outs[0].strip().splitlines()[-1])
-    assert res["ranges"] == [[0, 501], [501, 500]] and res["tmax"] == 1.5
+    assert res["ranges"] == [[0, 501], [501, 500]] and res["tmax"] == 1.5 and res["per_rank"] == [0.5, 1.5]
+
+
+def test_bench_self_launcher_rank_plan():
+    """`python bench.py --gpus N` (the form the driver uses) must start N ranks by itself: the parent prints the
+    plan with --launch-plan (no GPU, no torch import), one fresh child per GPU with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set; a WORLD_SIZE that disagrees with --gpus is refused instead of silently timing one GPU."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-plan", "--workload",
+                        "syn512", "--batch", "8192", "--cache"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["n_gpus"] == 8 and len(plan["ranks"]) == 8
+    ports = {p["env"]["MASTER_PORT"] for p in plan["ranks"]}
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    for i, p in enumerate(plan["ranks"]):
+        e = p["env"]
+        assert (p["rank"], e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"]) == (i, str(i), str(i), "8", "127.0.0.1")
+        assert p["cmd"][1].endswith("bench.py") and "--launch-plan" not in p["cmd"]
+        assert p["cmd"][2:] == ["--gpus", "8", "--workload", "syn512", "--batch", "8192", "--cache"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr
+
+
+def test_bench_self_launcher_relays_rank0_and_fails_on_child_failure(tmp_path, monkeypatch):
+    """The launcher itself, with stand-in children: rank 0's JSON line is relayed, a failing rank fails the run."""
+    import importlib
+    import io
+    import contextlib
+
+    bench = importlib.import_module("bench")
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, json\n"
+                     "r = int(os.environ['RANK'])\n"
+                     "if r == 0: print('noise'); print(json.dumps({'n_gpus': int(os.environ['WORLD_SIZE']), 'rank': r}))\n"
+                     "sys.exit(3 if os.environ.get('FAIL_RANK') == str(r) else 0)\n")
+
+    def fake_plan(n, argv, port):
+        return [{"rank": r, "cmd": [sys.executable, str(child)],
+                 "env": {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n)}} for r in range(n)]
+
+    monkeypatch.setattr(bench, "launch_plan", fake_plan)
+    args = bench.parse_args(["--gpus", "3"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        assert bench.self_launch(args, ["--gpus", "3"]) == 0
+    import json
+
+    assert json.loads(buf.getvalue().strip()) == {"n_gpus": 3, "rank": 0}
+    monkeypatch.setenv("FAIL_RANK", "2")
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert bench.self_launch(args, ["--gpus", "3"]) != 0
 
 
 def test_create_frequency_masks_golden():
@@ -301,3 +356,96 @@ def test_hermite_polynomials_known_answers():
     torch.testing.assert_close(H[3], 8 * s ** 3 - 12 * s)
     torch.testing.assert_close(H[4], 16 * s ** 4 - 48 * s ** 2 + 12)
     assert hermite_polynomials(torch.zeros(2, 3), 2).shape == (3, 2, 3)
+
+
+def test_hydra_surface_targets_resolve_and_instantiate():
+    """The north_star's "Hydra-config API surface": the reference pins it by composing and instantiating every
+    cmd/conf/*.yaml (tests/test_hydra_configs.py:21-51).  hydra / omegaconf are not installed here, so the same
+    check runs on tests/golden/hydra_targets.json -- the `_target_` strings, `_partial_` flags and kwargs extracted
+    from cmd/conf/{sampler,score_model,score_model/noise_scheduler}/*.yaml by oracle/gen_hydra_targets.py -- through
+    install_as_fdiff() and the package's own instantiate()."""
+    import functools
+    import json
+
+    import fastfourierdiffusion_amd as pkg
+    from fastfourierdiffusion_amd.utils.extraction import get_model_type, instantiate
+
+    pkg.install_as_fdiff(force=True)
+    tg = json.load(open(os.path.join(ROOT, "tests", "golden", "hydra_targets.json")))
+
+    def resolved(name, fourier):
+        e = tg[name]
+        cfg = {"_target_": e["_target_"], "_partial_": e["_partial_"]}
+        # OmegaConf reads `1e-5` as a float where PyYAML's YAML-1.1 resolver leaves a string
+        cfg.update({k: (float(v) if isinstance(v, str) and re.fullmatch(r"[0-9.]+e-?[0-9]+", v) else v)
+                    for k, v in e["kwargs"].items()})
+        for k in e["interpolated"]:  # ${fourier_transform} / ${score_model.fourier_noise_scaling}
+            cfg[k] = fourier
+        return cfg
+
+    assert tg["sample"]["use_cache"] is False and tg["sample"]["cache_kwargs"] == {}
+    for fourier in (True, False):
+        for model_cfg in ("score_model/default", "score_model/lstm", "score_model/mlp"):
+            for sched in ("vpsde", "vesde"):
+                cfg = resolved(model_cfg, fourier)
+                cfg["noise_scheduler"] = resolved(f"score_model/noise_scheduler/{sched}", fourier)
+                assert cfg["_target_"].startswith("fdiff.models.score_models.")
+                model_partial = instantiate(cfg)
+                assert isinstance(model_partial, functools.partial)
+                model = model_partial(n_channels=2, max_len=24, num_training_steps=10)  # cmd/train.py:47-51
+                assert type(model) is get_model_type({"score_model": cfg})
+                assert model.d_model == 72 and model.num_layers == 10 and model.scale_noise is fourier
+                sch = model.noise_scheduler
+                assert type(sch).__name__ == ("VPScheduler" if sched == "vpsde" else "VEScheduler")
+                assert sch.noise_scaling is fourier and sch.eps == 1e-5
+                if sched == "vpsde":
+                    assert (sch.beta_0, sch.beta_1) == (0.1, 20)  # sde.py:184-185
+                else:
+                    assert (sch.sigma_min, sch.sigma_max) == (0.01, 2)
+                sampler_partial = instantiate(resolved("sampler/default", fourier))
+                sampler = sampler_partial(score_model=model)  # cmd/sample.py:80-91
+                assert type(sampler).__module__.endswith("sampling.sampler") and sampler.sample_batch_size == 50
+                if model_cfg == "score_model/default":
+                    cached = sampler_partial(score_model=model, use_cache=True, cache_kwargs={"K": 3})
+                    assert cached.use_cache and model.cache.K == 3
+                    model.disable_caching()
+
+
+def test_extraction_helpers_on_a_synthetic_run_directory(tmp_path):
+    """utils/extraction.py:20-121 as cmd/sample.py:52-75 uses it: best checkpoint by val_loss, model class from the
+    training config, flatten / pretty-print.  No real lightning_logs exist here, so the tree is synthesised."""
+    from fastfourierdiffusion_amd.models.score_models import LSTMScoreModule, MLPScoreModule, ScoreModule
+    from fastfourierdiffusion_amd.utils import extraction as ex
+
+    ck = tmp_path / "lightning_logs" / "abc123" / "checkpoints"
+    ck.mkdir(parents=True)
+    for name in ("epoch=3-val_loss=0.52.ckpt", "epoch=17-val_loss=0.07.ckpt", "epoch=40-val_loss=0.30.ckpt",
+                 "last.ckpt", "epoch=99-val_loss=0.01.txt"):
+        (ck / name).write_bytes(b"")
+    assert ex.get_best_checkpoint(ck).name == "epoch=17-val_loss=0.07.ckpt"
+    with pytest.raises(UnboundLocalError):  # the reference returns an unbound local when nothing matches
+        ex.get_best_checkpoint(tmp_path)
+    for tgt, cls in (("ScoreModule", ScoreModule), ("MLPScoreModule", MLPScoreModule), ("LSTMScoreModule", LSTMScoreModule)):
+        assert ex.get_model_type({"score_model": {"_target_": f"fdiff.models.score_models.{tgt}"}}) is cls
+    with pytest.raises(NotImplementedError):
+        ex.get_model_type({"score_model": {"_target_": "fdiff.models.score_models.Other"}})
+    cfg = {"random_seed": 42, "fourier_transform": True,
+           "score_model": {"_target_": "fdiff.models.score_models.ScoreModule", "_partial_": True, "d_model": 72,
+                           "noise_scheduler": {"_target_": "fdiff.schedulers.sde.VPScheduler", "beta_min": 0.1}},
+           "trainer": {"callbacks": [{"_target_": "pl.callbacks.ModelCheckpoint", "monitor": "val/loss"},
+                                     {"_target_": "pl.callbacks.LearningRateMonitor"}], "max_epochs": 200}}
+    flat = ex.flatten_config(cfg)
+    assert flat == {"random_seed": 42, "fourier_transform": True, "score_model": "fdiff.models.score_models.ScoreModule",
+                    "d_model": 72, "noise_scheduler": "fdiff.schedulers.sde.VPScheduler", "beta_min": 0.1,
+                    "callbacks": ["pl.callbacks.ModelCheckpoint", "pl.callbacks.LearningRateMonitor"],
+                    "monitor": "val/loss", "max_epochs": 200}
+    text = ex.dict_to_str({"a": 1, "long_list": [1, 2, 3, 4, 5]})
+    assert "[1, 2, 3, '...']" in text and text.count("\n") == 2
+
+    class DM:
+        dataset_parameters = {"n_channels": 1, "max_len": 187, "num_training_steps": 100}
+
+    class TR:
+        max_epochs, accumulate_grad_batches = 200, 4
+
+    assert ex.get_training_params(DM(), TR())["num_training_steps"] == 5000

@@ -243,3 +243,59 @@ def test_extra_traj_golden(golden, c):
     ref = golden["g11_extra_traj"][c["name"]]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
+
+
+# ---- G12 (round 2): per-sample timesteps, config-5-shaped cached trajectory, two samplers, affine (i)dft ----
+@pytest.mark.parametrize("c", cases.MIXED_T_CASES, ids=lambda c: c["name"])
+def test_mixed_timesteps_golden(golden, c):
+    g = golden["g12_round2"]
+    sd = make_sd(c)
+    B, L, C = c["B"], c["L"], c["C"]
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+    t = torch.tensor(c["t"], dtype=torch.float32)  # integer timesteps promote to fp32 in timesteps * W (transformer.py:80)
+    sc = O.lstm_score_forward(x, t, sd, c["NL"]) if c["kind"] == "lstm" else O.score_forward(x, t, sd, c["NL"], c["H"])
+    assert rel_err(sc, g[c["name"] + "_score"]) < TOL_KERNEL * 5
+    if c.get("recompute"):
+        table = O.KVTable(c["NL"], L)
+        for j, rec in enumerate(c["recompute"]):
+            xj = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"] + 100 + j)))
+            sc, crf = O.score_forward(xj, t, sd, c["NL"], c["H"], table, rec, return_crf=True)
+            assert rel_err(sc, g[f"{c['name']}_cseq{j}_score"]) < TOL_KERNEL * 5, j
+            assert rel_err(crf, g[f"{c['name']}_cseq{j}_crf"]) < TOL_KERNEL * 5, j
+
+
+def _oracle_sample(c, zseed, ck):
+    sd = make_sd(c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), zseed))
+    return O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=c["sde"],
+                    sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"], num_samples=c["num_samples"],
+                    batch_size=B, num_steps=N, noise=noise, use_cache=True, K=ck.get("K", 5), R=ck.get("R", 10))
+
+
+@pytest.mark.parametrize("c", cases.SYN_TRAJ_CASES, ids=lambda c: c["name"])
+def test_syn_traj_golden(golden, c):
+    out = _oracle_sample(c, c["zseed"], c["cache_kwargs"])
+    assert rel_err(out, golden["g12_round2"][c["name"]]) < TOL_TRAJ
+
+
+def test_two_samplers_golden(golden):
+    """Each sampler on a shared model behaves like a fresh run with ITS cache's K / R: step 0 rewrites the tables
+    the layers stay bound to (Q5), so the first sampler's configuration leaves no trace in the second's samples."""
+    c = cases.TWO_SAMPLER_CASE
+    g = golden["g12_round2"]
+    assert rel_err(_oracle_sample(c, c["zseed1"], c["first_kwargs"]), g["two_samplers_first"]) < TOL_TRAJ
+    assert rel_err(_oracle_sample(c, c["zseed2"], c["second_kwargs"]), g["two_samplers_second"]) < TOL_TRAJ
+    # the second sampler's own cache object never sees a hit or a recompute (Q5)
+    np.testing.assert_array_equal(g["two_samplers_second_stats"], [0, 0])
+
+
+@pytest.mark.parametrize("case", cases.AFFINE_FFT_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
+def test_affine_fft_golden(golden, case):
+    L, C, B, seed = case
+    x, mean, std = (torch.from_numpy(a) for a in synthetic.noise_stream((B, L, C), 3, seed))
+    mean, std = mean[0], std[0].abs() + 0.5
+    g = golden["g12_round2"]
+    assert rel_err(O.unstandardize_idft(x, mean, std), g[f"unstd_idft_L{L}_C{C}"]) < TOL_KERNEL
+    assert rel_err(O.dft_standardize(x, mean, std), g[f"dft_std_L{L}_C{C}"]) < TOL_KERNEL
