@@ -81,6 +81,8 @@ SIGNATURES = {
     "ffd_prior": (C.c_int, [C.POINTER(SdeDesc), _P, _P, _P, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_dft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_idft": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ffd_unstandardize_idft": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "ffd_dft_standardize": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_positional_encoding": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ffd_time_encoding": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_fresca": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double, C.c_int, _P]),

@@ -120,6 +120,7 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
 }
 
 static int g_bench_kernel = 0;
+static int g_fuse_tail = 1;
 
 // HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
 struct Timed {
@@ -180,6 +181,15 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "bench_kernel")) {  // what ffd_bench_ffn times: 0 k_ffn_ln, 1 k_layer, 2 k_layer + next QKV
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_bench_kernel = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_mfma_min_batch")) {  // batch from which the batch-tiled MFMA recurrence is used
+    if (value < 1) return FFD_ERR_INVALID;
+    g_lstm_mfma_min_batch = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "fuse_tail")) {  // unembed inside the SDE-step kernel of ffd_sample_batch
+    g_fuse_tail = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "fuse_layer")) {
@@ -519,8 +529,10 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
 // one score evaluation; temb points at d floats on the device (temb_stride = 0: shared by the batch) or at a
 // (B, d) table (temb_stride = d: per-sample diffusion times).
 // n_rec < 0: no cache.  Otherwise the E2-CRF mode for |recompute_tokens| = n_rec.
+// hidden_out != nullptr (transformer / LSTM): skip the unembedding and return the final hidden state (M x d) instead;
+// the sampling loop unembeds inside the SDE-step kernel.
 static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int temb_stride, float* score_out,
-                        float* crf_out, int B, int n_rec, hipStream_t s) {
+                        float* crf_out, int B, int n_rec, hipStream_t s, const float** hidden_out = nullptr) {
   const ffd_model_desc& m = ctx->desc;
   const int L = m.max_len, C = m.n_channels, d = m.d_model, M = B * L;
   if (m.kind == FFD_MODEL_MLP) {  // MLPScoreModule.forward, score_models.py:406-440
@@ -550,8 +562,16 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
                                     temb_stride, ctx->h0, B, L, C, d, s));
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];
+      if (lstm_mfma_selected(B, d)) {  // batch-tiled MFMA recurrence with the input gates fused
+        TIMED(FFD_K_LSTM_REC, launch_lstm_mfma(ctx->h0, l.wih, l.whh, l.bsum, B, L, d, s));
+        continue;
+      }
       TIMED(FFD_K_LSTM_GATES, launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
       TIMED(FFD_K_LSTM_REC, launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
+    }
+    if (hidden_out) {
+      *hidden_out = ctx->h0;
+      return FFD_OK;
     }
     TIMED(FFD_K_UNEMBED, launch_unembed(ctx->h0, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p,
                                         score_out, M, C, d, s));
@@ -635,6 +655,10 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       ctx->stats.recompute_count += (int64_t)n_rec * m.num_layers;
       ctx->table_allocated = true;
     }
+  }
+  if (hidden_out) {
+    *hidden_out = cur;
+    return FFD_OK;
   }
   TIMED(FFD_K_UNEMBED, launch_unembed(cur, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, score_out,
                                       M, C, d, s));
@@ -748,13 +772,27 @@ int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G,
 
 int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream) {
   if (!in || !out || in == out || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
-  hipError_t e = launch_dft(in, out, B, L, C, 0, (hipStream_t)stream);
+  hipError_t e = launch_dft(in, out, B, L, C, 0, nullptr, nullptr, (hipStream_t)stream);
   return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
 }
 
 int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream) {
   if (!in || !out || in == out || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
-  hipError_t e = launch_dft(in, out, B, L, C, 1, (hipStream_t)stream);
+  hipError_t e = launch_dft(in, out, B, L, C, 1, nullptr, nullptr, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+int ffd_dft_standardize(const float* in, float* out, const float* mean, const float* std, int B, int L, int C,
+                        void* stream) {
+  if (!in || !out || in == out || !mean || !std || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  hipError_t e = launch_dft(in, out, B, L, C, 0, mean, std, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
+int ffd_unstandardize_idft(const float* in, float* out, const float* mean, const float* std, int B, int L, int C,
+                           void* stream) {
+  if (!in || !out || in == out || !mean || !std || B < 0 || L < 1 || C < 1) return FFD_ERR_INVALID;
+  hipError_t e = launch_dft(in, out, B, L, C, 1, std, mean, (hipStream_t)stream);
   return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
 }
 
@@ -1013,6 +1051,11 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   }
   const size_t slab = (size_t)B * m.max_len * m.n_channels;
   const uint64_t elem_off = sample_offset * (uint64_t)m.max_len * m.n_channels;
+  // Without FreSca the score is consumed only by the SDE step: unembed inside the step kernel (one launch and a
+  // (B, L, C) round trip less per step).  FreSca needs the whole score (FFT along L).
+  const bool fuse_tail = g_fuse_tail && !ctx->fresca_on && m.kind != FFD_MODEL_MLP &&
+                         unembed_sde_supported(m.n_channels, d) && (m.n_channels % 4 != 0 || elem_off % 4 == 0) &&
+                         (!z_inject || (reinterpret_cast<uintptr_t>(z_inject) % 16 == 0 && slab % 4 == 0));
   for (int j = 0; j < n_run; ++j) {
     const int i = first_step + j;
     int n_rec = -1;
@@ -1036,7 +1079,10 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
         }
       }
     }
-    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, 0, ctx->score, crf_dst, B, n_rec, s))) return rc;
+    const float* hidden = nullptr;
+    if ((rc = forward_impl(ctx, x, ctx->temb_tab + (size_t)i * d, 0, ctx->score, crf_dst, B, n_rec, s,
+                           fuse_tail ? &hidden : nullptr)))
+      return rc;
     if (crf_copy)
       HIPCHECK(hipMemcpyAsync(crf_copy, crf_dst, sizeof(float) * (size_t)m.num_layers * m.max_len * d,
                               hipMemcpyDeviceToDevice, s));
@@ -1053,9 +1099,15 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
         score = ctx->score2;
       }
     }
-    TIMED(FFD_K_SDE, launch_sde_step(x, score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
-                                     sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B,
-                                     m.max_len, m.n_channels, s));
+    if (hidden)
+      TIMED(FFD_K_SDE, launch_unembed_sde(hidden, ctx->raw["unembedder.weight"].p, ctx->raw["unembedder.bias"].p, x,
+                                          z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
+                                          sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i,
+                                          B, m.max_len, m.n_channels, d, s));
+    else
+      TIMED(FFD_K_SDE, launch_sde_step(x, score, z_inject ? z_inject + (size_t)j * slab : nullptr, ctx->G_dev,
+                                       sde_params(m.sde, m.sde_a, m.sde_b, t, step_size), seed, elem_off, (uint32_t)i, B,
+                                       m.max_len, m.n_channels, s));
   }
   return FFD_OK;
 }
@@ -1145,14 +1197,23 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
       if (tr) name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
-    case FFD_K_LSTM_REC:  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out
-      if (ls) name = "k_lstm_layer", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * 4.0 * d + 2.0 * M * d + 4.0 * d * d);
+    case FFD_K_LSTM_REC:
+      if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
+        name = "k_lstm_mfma", fl = 2.0 * M * 8.0 * d * d, by = 4.0 * (2.0 * M * d + 8.0 * d * d);
+      else if (ls)  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out
+        name = "k_lstm_layer", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * 4.0 * d + 2.0 * M * d + 4.0 * d * d);
       break;
     case FFD_K_LSTM_GATES:
-      if (ls) name = "k_linear_rm", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * d + M * 4.0 * d + 4.0 * d * d);
+      if (ls && !lstm_mfma_selected(B, m.d_model))
+        name = "k_linear_rm", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * d + M * 4.0 * d + 4.0 * d * d);
       break;
-    case FFD_K_SDE:  // x, score in; x out (noise generated on chip): 12 B per element
-      name = "k_sde_step", by = 12.0 * M * C;
+    case FFD_K_SDE:
+      // x, score in; x out (noise generated on chip): 12 B per element; with the unembedding fused
+      // into it the score term is replaced by the hidden row: 4 (d + 2 C) B per row
+      if (g_fuse_tail && !ctx->fresca_on && m.kind != FFD_MODEL_MLP && unembed_sde_supported(m.n_channels, m.d_model))
+        name = "k_unembed_mfma<sde>", fl = 2.0 * M * C * d, by = 4.0 * M * (d + 2.0 * C);
+      else
+        name = "k_sde_step", by = 12.0 * M * C;
       break;
     case FFD_K_EMBED:
       if (m.kind != FFD_MODEL_MLP) name = "k_embed", fl = 2.0 * M * C * d, by = 4.0 * M * (C + d);

@@ -138,14 +138,66 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 }
 
 // ---------------------------------------------------------------------------
-// embed: h[row][j] = be[j] + sum_c X[row][c] We[j][c] (+ pos[l][j]) + temb[j]
+// embed: h[row][j] = be[j] + sum_c X[row][c] We[j][c] (+ pos[l][j]) + temb[b][j]
 // ---------------------------------------------------------------------------
+// Write-bound (4 (C + D) bytes per row, D >> C).  k_embed_reg (C <= 8): the grid is sized so that every thread keeps
+// ONE float4 column j of the output for its whole grid-stride loop (threads % (D/4) == 0): its 4 x C embedder weights,
+// bias and (shared) time embedding stay in registers, (b, l) of its row advance incrementally -- the loop body is the
+// row's x (C floats, float4 loads when C % 4 == 0; the D/4 threads of a row share them through L1), 4 C FMAs, one
+// positional float4 (L2-resident table) and one coalesced float4 store.  No LDS, no integer division in the loop.
+template <bool XVEC>
+__global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, const float* __restrict__ We,
+                                                   const float* __restrict__ be, const float* __restrict__ pos,
+                                                   const float* __restrict__ temb, int temb_stride,
+                                                   float* __restrict__ h, unsigned M, int L, int C, int D) {
+  const unsigned D4 = (unsigned)D >> 2;
+  const unsigned T = gridDim.x * blockDim.x;          // multiple of D4 (launcher)
+  const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned rs = T / D4;                         // rows advanced per iteration
+  unsigned row = g / D4;
+  const int j = (int)(g - row * D4) << 2;
+  float4 w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    w[c] = c < C ? float4{We[(j + 0) * C + c], We[(j + 1) * C + c], We[(j + 2) * C + c], We[(j + 3) * C + c]}
+                 : float4{0.f, 0.f, 0.f, 0.f};
+  const float4 bias = *reinterpret_cast<const float4*>(be + j);
+  unsigned b = row / (unsigned)L, l = row - b * (unsigned)L;
+  const unsigned qb = rs / (unsigned)L, rl = rs - qb * (unsigned)L;
+  for (; row < M; row += rs) {
+    float xv[8];
+    const float* x = X + (size_t)row * C;
+    if (XVEC) {
+      const float4 a = *reinterpret_cast<const float4*>(x);
+      xv[0] = a.x, xv[1] = a.y, xv[2] = a.z, xv[3] = a.w;
+      if (C > 4) {
+        const float4 a2 = *reinterpret_cast<const float4*>(x + 4);
+        xv[4] = a2.x, xv[5] = a2.y, xv[6] = a2.z, xv[7] = a2.w;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) xv[c] = c < C ? x[c] : 0.f;
+    }
+    float4 v = bias;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) v.x = fmaf(xv[c], w[c].x, v.x), v.y = fmaf(xv[c], w[c].y, v.y), v.z = fmaf(xv[c], w[c].z, v.z), v.w = fmaf(xv[c], w[c].w, v.w);
+    if (pos) {
+      const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)l * D + j);
+      v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+    }
+    const float4 t = *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j);
+    *reinterpret_cast<float4*>(h + (size_t)row * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
+    l += rl, b += qb;
+    if (l >= (unsigned)L) l -= (unsigned)L, ++b;
+  }
+}
+
 __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ We, const float* __restrict__ be,
                         const float* __restrict__ pos, const float* __restrict__ temb, int temb_stride,
                         float* __restrict__ h, unsigned total4, int L, int C, int D) {
-  // The (D x C) embedder weight is staged transposed in LDS ([c][j]), so the C weights of an output float4 are C
-  // aligned 16-byte LDS reads instead of 4 C scattered global loads.  One float4 of h per thread and iteration
-  // (D % 4 == 0); 32-bit index math only; same operation order as before the staging.
+  // generic C: the (D x C) embedder weight is staged transposed in LDS ([c][j]); one float4 of h per thread and
+  // iteration (D % 4 == 0); same operation order as k_embed_reg.
   extern __shared__ __align__(16) float wt[];  // C * D floats
   for (int i = threadIdx.x; i < C * D; i += blockDim.x) {
     const int c = i / D, j = i - c * D;
@@ -175,7 +227,21 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
 
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
                         int temb_stride, float* h, int B, int L, int C, int D, hipStream_t s) {
-  const unsigned total4 = (unsigned)((size_t)B * L * D / 4);
+  const unsigned M = (unsigned)B * (unsigned)L;
+  const unsigned total4 = (unsigned)((size_t)M * D / 4);
+  if (C <= 8 && D % 4 == 0) {
+    // threads = blocks * 256 must be a multiple of D/4: blocks = multiple of (D/4) / gcd(D/4, 256)
+    unsigned D4 = (unsigned)D / 4, gcd = D4, r = 256;
+    while (r) { const unsigned t = gcd % r; gcd = r; r = t; }
+    const unsigned unit = D4 / gcd;
+    unsigned blocks = (total4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    blocks = ((blocks + unit - 1) / unit) * unit;
+    const bool xvec = (C == 4 || C == 8) && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
+    if (xvec) hipLaunchKernelGGL(k_embed_reg<true>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, M, L, C, D);
+    else hipLaunchKernelGGL(k_embed_reg<false>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, M, L, C, D);
+    return hipGetLastError();
+  }
   unsigned blocks = (total4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;  // grid-stride: the weight staging is amortised over >= a few rows per thread
   const size_t lds = (size_t)C * D * sizeof(float);
@@ -230,47 +296,6 @@ hipError_t launch_renorm_rows_once(float* W, int rows, int D, float max_norm, hi
 }
 
 // ---------------------------------------------------------------------------
-// unembed: score[row][c] = bu[c] + h[row][:] . Wu[c][:]   (16 lanes per row)
-// ---------------------------------------------------------------------------
-__global__ void k_unembed(const float* __restrict__ h, const float* __restrict__ Wu, const float* __restrict__ bu,
-                          float* __restrict__ score, int M, int C, int D) {
-  // The row's D values are read once into registers (lane `sub` of the row's 16 holds k = sub, sub+16, ...), the
-  // (C x D) weight sits in LDS; per channel: <= 8 FMAs and a 16-lane xor reduction.  D <= 128.
-  extern __shared__ float wl[];  // C * D
-  for (int i = threadIdx.x; i < C * D; i += blockDim.x) wl[i] = Wu[i];
-  __syncthreads();
-  constexpr int NI = 8;
-  const int sub = threadIdx.x & 15;
-  const int rows_per_block = blockDim.x >> 4;
-  for (int row = blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < M; row += gridDim.x * rows_per_block) {
-    const float* hr = h + (size_t)row * D;
-    float hv[NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) hv[i] = (sub + 16 * i < D) ? hr[sub + 16 * i] : 0.f;
-    for (int c = 0; c < C; ++c) {
-      float acc = 0.f;
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-        if (16 * i < D) acc = fmaf(hv[i], (sub + 16 * i < D) ? wl[c * D + sub + 16 * i] : 0.f, acc);
-      acc += __shfl_xor(acc, 8, 16);
-      acc += __shfl_xor(acc, 4, 16);
-      acc += __shfl_xor(acc, 2, 16);
-      acc += __shfl_xor(acc, 1, 16);
-      if (sub == 0) score[(size_t)row * C + c] = acc + bu[c];
-    }
-  }
-}
-
-hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, float* score, int M, int C, int D,
-                          hipStream_t s) {
-  if (D > 128 || (size_t)C * D * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
-  int blocks = cdiv(M, 16);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_unembed, dim3(blocks), dim3(256), (size_t)C * D * sizeof(float), s, h, Wu, bu, score, M, C, D);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller
 // ---------------------------------------------------------------------------
 struct U4 {
@@ -291,14 +316,15 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
   return c;
 }
 
+// Two N(0,1) draws from two 32-bit words.  The hardware transcendentals (v_log_f32 = log2, v_sin_f32 / v_cos_f32 take
+// their argument in revolutions, i.e. u2 itself) keep the generator off the critical path of the HBM-bound step
+// kernel: the library logf / sincosf cost ~10x the instructions and made the step ALU-bound (2.8 TB/s).
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
-  float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-  float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-  float r = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincosf(6.28318530717958647692f * u2, &s, &c);
-  z0 = r * c;
-  z1 = r * s;
+  const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+  const float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+  z0 = r * __builtin_amdgcn_cosf(u2);
+  z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 // N(0,1) for global element index g at (seed, stream tag `step`): slot g&3 of Philox(counter g>>2).
@@ -309,6 +335,7 @@ __device__ __forceinline__ void normal4(uint64_t g4, uint64_t seed, uint32_t ste
   box_muller(r.z, r.w, out[2], out[3]);
 }
 
+// the (up to) 4 draws of elements i0 .. i0+3 (global index elem_offset + i0, any alignment), or injected ones
 __device__ __forceinline__ void load_normals(const float* z, size_t i0, int n, uint64_t seed, uint64_t elem_offset,
                                              uint32_t step, float zz[4]) {
   if (z) {
@@ -334,6 +361,37 @@ __device__ __forceinline__ void load_normals(const float* z, size_t i0, int n, u
 //   VP: drift = a*x - (g*g)*s ;  x' = (x - drift*dt) + sqdt*(g*z),  g = cs*G[l]
 //   VE: drift = -((g*g)*s)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float sde_update(float xi, float sc, float Gl, float zz, const SdeParams& p) {
+  const float g = __fmul_rn(p.cs, Gl);
+  const float g2 = __fmul_rn(g, g);
+  const float gs = __fmul_rn(g2, sc);
+  const float drift = (p.sde == 0) ? __fsub_rn(__fmul_rn(p.a, xi), gs) : -gs;
+  const float t1 = __fsub_rn(xi, __fmul_rn(drift, p.dt));
+  return __fadd_rn(t1, __fmul_rn(p.sqdt, __fmul_rn(g, zz)));
+}
+
+// C % 4 == 0, 16-byte aligned buffers: one float4 of x / score (/ z) per thread and iteration; the four elements
+// share their row, so G[l] is one load; the draws of an aligned quad are one Philox block.  12 B per element.
+__global__ __launch_bounds__(256) void k_sde_step_v4(float* __restrict__ x, const float* __restrict__ score,
+                                                     const float* __restrict__ z, const float* __restrict__ G,
+                                                     SdeParams p, uint64_t seed, uint64_t elem_offset, uint32_t step,
+                                                     size_t nvec, int L, unsigned C4) {
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    const float4 xi = reinterpret_cast<const float4*>(x)[v];
+    const float4 sc = reinterpret_cast<const float4*>(score)[v];
+    float zz[4];
+    if (z) {
+      const float4 zv = reinterpret_cast<const float4*>(z)[v];
+      zz[0] = zv.x, zz[1] = zv.y, zz[2] = zv.z, zz[3] = zv.w;
+    } else {
+      normal4((elem_offset >> 2) + v, seed, step, zz);  // elem_offset is a multiple of C
+    }
+    const float Gl = G[(v / C4) % (size_t)L];
+    reinterpret_cast<float4*>(x)[v] = float4{sde_update(xi.x, sc.x, Gl, zz[0], p), sde_update(xi.y, sc.y, Gl, zz[1], p),
+                                             sde_update(xi.z, sc.z, Gl, zz[2], p), sde_update(xi.w, sc.w, Gl, zz[3], p)};
+  }
+}
+
 __global__ void k_sde_step(float* __restrict__ x, const float* __restrict__ score, const float* __restrict__ z,
                            const float* __restrict__ G, SdeParams p, uint64_t seed, uint64_t elem_offset,
                            uint32_t step, size_t total, int L, int C) {
@@ -346,16 +404,12 @@ __global__ void k_sde_step(float* __restrict__ x, const float* __restrict__ scor
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
       const int l = (int)((i / (size_t)C) % (size_t)L);
-      float g = __fmul_rn(p.cs, G[l]);
-      float g2 = __fmul_rn(g, g);
-      float xi = x[i];
-      float gs = __fmul_rn(g2, score[i]);
-      float drift = (p.sde == 0) ? __fsub_rn(__fmul_rn(p.a, xi), gs) : -gs;
-      float t1 = __fsub_rn(xi, __fmul_rn(drift, p.dt));
-      x[i] = __fadd_rn(t1, __fmul_rn(p.sqdt, __fmul_rn(g, zz[j])));
+      x[i] = sde_update(x[i], score[i], G[l], zz[j], p);
     }
   }
 }
+
+static bool ptr16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 hipError_t launch_sde_step(float* x, const float* score, const float* z, const float* G, SdeParams p, uint64_t seed,
                            uint64_t elem_offset, uint32_t step, int B, int L, int C, hipStream_t s) {
@@ -363,9 +417,36 @@ hipError_t launch_sde_step(float* x, const float* score, const float* z, const f
   size_t blocks = ((total + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_sde_step, dim3((unsigned)blocks), dim3(256), 0, s, x, score, z, G, p, seed, elem_offset, step,
-                     total, L, C);
+  if (C % 4 == 0 && ptr16(x) && ptr16(score) && ptr16(z) && elem_offset % 4 == 0)
+    hipLaunchKernelGGL(k_sde_step_v4, dim3((unsigned)blocks), dim3(256), 0, s, x, score, z, G, p, seed, elem_offset, step,
+                       total / 4, L, (unsigned)C / 4);
+  else
+    hipLaunchKernelGGL(k_sde_step, dim3((unsigned)blocks), dim3(256), 0, s, x, score, z, G, p, seed, elem_offset, step,
+                       total, L, C);
   return hipGetLastError();
+}
+
+// prior: x = G (.) z  (VE: * sigma_max), sde.py:79-87,125-127
+__device__ __forceinline__ float prior_value(float Gl, float zz, float scale) {
+  const float v0 = __fmul_rn(Gl, zz);
+  return (scale == 1.0f) ? v0 : __fmul_rn(scale, v0);
+}
+
+__global__ __launch_bounds__(256) void k_prior_v4(float* __restrict__ x, const float* __restrict__ z,
+                                                  const float* __restrict__ G, float scale, uint64_t seed,
+                                                  uint64_t elem_offset, size_t nvec, int L, unsigned C4) {
+  for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (size_t)gridDim.x * blockDim.x) {
+    float zz[4];
+    if (z) {
+      const float4 zv = reinterpret_cast<const float4*>(z)[v];
+      zz[0] = zv.x, zz[1] = zv.y, zz[2] = zv.z, zz[3] = zv.w;
+    } else {
+      normal4((elem_offset >> 2) + v, seed, 0xFFFFFFFFu, zz);
+    }
+    const float Gl = G[(v / C4) % (size_t)L];
+    reinterpret_cast<float4*>(x)[v] = float4{prior_value(Gl, zz[0], scale), prior_value(Gl, zz[1], scale),
+                                             prior_value(Gl, zz[2], scale), prior_value(Gl, zz[3], scale)};
+  }
 }
 
 __global__ void k_prior(float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ G, float scale,
@@ -379,8 +460,7 @@ __global__ void k_prior(float* __restrict__ x, const float* __restrict__ z, cons
     for (int j = 0; j < n; ++j) {
       size_t i = i0 + j;
       const int l = (int)((i / (size_t)C) % (size_t)L);
-      float v0 = __fmul_rn(G[l], zz[j]);
-      x[i] = (scale == 1.0f) ? v0 : __fmul_rn(scale, v0);
+      x[i] = prior_value(G[l], zz[j], scale);
     }
   }
 }
@@ -391,8 +471,174 @@ hipError_t launch_prior(float* x, const float* z, const float* G, float scale, u
   size_t blocks = ((total + 3) / 4 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(k_prior, dim3((unsigned)blocks), dim3(256), 0, s, x, z, G, scale, seed, elem_offset, total, L, C);
+  if (C % 4 == 0 && ptr16(x) && ptr16(z) && elem_offset % 4 == 0)
+    hipLaunchKernelGGL(k_prior_v4, dim3((unsigned)blocks), dim3(256), 0, s, x, z, G, scale, seed, elem_offset, total / 4, L,
+                       (unsigned)C / 4);
+  else
+    hipLaunchKernelGGL(k_prior, dim3((unsigned)blocks), dim3(256), 0, s, x, z, G, scale, seed, elem_offset, total, L, C);
   return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// unembed: score[row][c] = bu[c] + h[row][:] . Wu[c][:]     (score_models.py:113)
+// and, fused, the reverse SDE step on that score (the score never reaches HBM).
+// ---------------------------------------------------------------------------
+// HBM-bound on the read of h (4 D bytes per row against 4 C written).  One wave owns 16 rows per iteration and forms
+// score^T (C x 16) on the exact-fp32 matrix core: A = the unembedder weight (channel on the row index, rows >= C
+// zero), B = the h rows, each lane loading FOUR consecutive k of its row as one float4 per 16-wide k chunk (the
+// MFMA's k index is then a permutation of the chunk's 16 k values, the same for A and B; the qkv kernel's trick).
+// The accumulator leaves lane l with channels 4 (l >> 4) .. +3 of row (l & 15): exactly one float4 of score / x
+// when C % 4 == 0.  SDE = true continues with the Euler-Maruyama update of x in those registers (same sde_update,
+// same Philox indexing as k_sde_step); SDE = false stores the score.  The next tile's h is prefetched under the
+// current tile's MFMAs and epilogue.
+template <int D, bool SDE>
+__global__ __launch_bounds__(256) void k_unembed_mfma(const float* __restrict__ h, const float* __restrict__ Wu,
+                                                      const float* __restrict__ bu, float* __restrict__ score,
+                                                      float* __restrict__ x, const float* __restrict__ z,
+                                                      const float* __restrict__ G, SdeParams p, uint64_t seed,
+                                                      uint64_t elem_offset, uint32_t step, int M, int L, int C) {
+  constexpr int NG = (D + 15) / 16;  // 16-wide k chunks
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 15, q = lane >> 4;
+  const int ntiles = (M + 15) >> 4;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  float4 wf[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    const int k = 16 * g + 4 * q;
+    wf[g] = (r < C && k < D) ? *reinterpret_cast<const float4*>(Wu + (size_t)r * D + k) : float4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 bias;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bias[i] = (4 * q + i < C) ? bu[4 * q + i] : 0.f;
+  auto load_tile = [&](int t, float4 (&hv)[NG]) {
+    const int row = min(16 * t + r, M - 1);
+    const float* hr = h + (size_t)row * D + 4 * q;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      hv[g] = (16 * g + 4 * q < D) ? *reinterpret_cast<const float4*>(hr + 16 * g) : float4{0.f, 0.f, 0.f, 0.f};
+  };
+  float4 hv[NG], hn[NG];
+  if (wave < ntiles) load_tile(wave, hv);
+  for (int t = wave; t < ntiles; t += nwaves) {
+    const bool more = t + nwaves < ntiles;
+    if (more) load_tile(t + nwaves, hn);
+    f32x4 acc = bias;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc = mfma16(wf[g].x, hv[g].x, acc);
+      acc = mfma16(wf[g].y, hv[g].y, acc);
+      acc = mfma16(wf[g].z, hv[g].z, acc);
+      acc = mfma16(wf[g].w, hv[g].w, acc);
+    }
+    const int row = 16 * t + r;
+    const int c0 = 4 * q;
+    if (row < M && c0 < C) {
+      const size_t i0 = (size_t)row * C + c0;
+      const int n = min(4, C - c0);
+      if (!SDE) {
+        if ((C & 3) == 0) *reinterpret_cast<float4*>(score + i0) = float4{acc[0], acc[1], acc[2], acc[3]};
+        else
+          for (int i = 0; i < n; ++i) score[i0 + i] = acc[i];
+      } else {
+        const float Gl = G[row % L];
+        float zz[4];
+        if ((C & 3) == 0) {
+          const float4 xi = *reinterpret_cast<const float4*>(x + i0);
+          if (z) {
+            const float4 zv = *reinterpret_cast<const float4*>(z + i0);
+            zz[0] = zv.x, zz[1] = zv.y, zz[2] = zv.z, zz[3] = zv.w;
+          } else {
+            normal4((elem_offset + i0) >> 2, seed, step, zz);
+          }
+          *reinterpret_cast<float4*>(x + i0) = float4{sde_update(xi.x, acc[0], Gl, zz[0], p), sde_update(xi.y, acc[1], Gl, zz[1], p),
+                                                      sde_update(xi.z, acc[2], Gl, zz[2], p), sde_update(xi.w, acc[3], Gl, zz[3], p)};
+        } else {
+          load_normals(z, i0, n, seed, elem_offset, step, zz);
+          for (int i = 0; i < n; ++i) x[i0 + i] = sde_update(x[i0 + i], acc[i], Gl, zz[i], p);
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) hv[g] = hn[g];
+    }
+  }
+}
+
+// generic fallback (C > 16): 16 lanes per row, weight in LDS
+__global__ void k_unembed(const float* __restrict__ h, const float* __restrict__ Wu, const float* __restrict__ bu,
+                          float* __restrict__ score, int M, int C, int D) {
+  extern __shared__ float wl[];  // C * D
+  for (int i = threadIdx.x; i < C * D; i += blockDim.x) wl[i] = Wu[i];
+  __syncthreads();
+  constexpr int NI = 8;
+  const int sub = threadIdx.x & 15;
+  const int rows_per_block = blockDim.x >> 4;
+  for (int row = blockIdx.x * rows_per_block + (threadIdx.x >> 4); row < M; row += gridDim.x * rows_per_block) {
+    const float* hr = h + (size_t)row * D;
+    float hv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) hv[i] = (sub + 16 * i < D) ? hr[sub + 16 * i] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+        if (16 * i < D) acc = fmaf(hv[i], (sub + 16 * i < D) ? wl[c * D + sub + 16 * i] : 0.f, acc);
+      acc += __shfl_xor(acc, 8, 16);
+      acc += __shfl_xor(acc, 4, 16);
+      acc += __shfl_xor(acc, 2, 16);
+      acc += __shfl_xor(acc, 1, 16);
+      if (sub == 0) score[(size_t)row * C + c] = acc + bu[c];
+    }
+  }
+}
+
+bool unembed_sde_supported(int C, int D) {
+  if (C > 16 || D % 4 != 0) return false;
+#define X(v) if (D == v) return true;
+  FFD_D_LIST(X)
+#undef X
+  return false;
+}
+
+template <bool SDE>
+static hipError_t launch_unembed_mfma(const float* h, const float* Wu, const float* bu, float* score, float* x,
+                                      const float* z, const float* G, SdeParams p, uint64_t seed, uint64_t elem_offset,
+                                      uint32_t step, int M, int L, int C, int D, hipStream_t s) {
+  int blocks = cdiv(cdiv(M, 16), 4);
+  if (blocks > 2048) blocks = 2048;
+  switch (D) {
+#define X(d)                                                                                                     \
+  case d:                                                                                                        \
+    hipLaunchKernelGGL((k_unembed_mfma<d, SDE>), dim3(blocks), dim3(256), 0, s, h, Wu, bu, score, x, z, G, p, seed, \
+                       elem_offset, step, M, L, C);                                                              \
+    break;
+    FFD_D_LIST(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, float* score, int M, int C, int D,
+                          hipStream_t s) {
+  if (unembed_sde_supported(C, D) && ptr16(h) && ptr16(Wu) && ptr16(score))
+    return launch_unembed_mfma<false>(h, Wu, bu, score, nullptr, nullptr, nullptr, SdeParams{}, 0, 0, 0, M, 1, C, D, s);
+  if (D > 128 || (size_t)C * D * sizeof(float) > 64 * 1024) return hipErrorInvalidValue;
+  int blocks = cdiv(M, 16);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_unembed, dim3(blocks), dim3(256), (size_t)C * D * sizeof(float), s, h, Wu, bu, score, M, C, D);
+  return hipGetLastError();
+}
+
+// x <- SDE step(x, unembed(h)): the fused tail of a sampling step (requires unembed_sde_supported(C, D))
+hipError_t launch_unembed_sde(const float* h, const float* Wu, const float* bu, float* x, const float* z, const float* G,
+                              SdeParams p, uint64_t seed, uint64_t elem_offset, uint32_t step, int B, int L, int C,
+                              int D, hipStream_t s) {
+  if (!unembed_sde_supported(C, D) || !ptr16(h) || !ptr16(Wu) || !ptr16(x) || !ptr16(z)) return hipErrorInvalidValue;
+  if ((C & 3) == 0 && (elem_offset & 3)) return hipErrorInvalidValue;
+  return launch_unembed_mfma<true>(h, Wu, bu, nullptr, x, z, G, p, seed, elem_offset, step, B * L, L, C, D, s);
 }
 
 // ---------------------------------------------------------------------------

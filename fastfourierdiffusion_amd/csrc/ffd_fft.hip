@@ -11,6 +11,9 @@
 //
 // Packed layout (fourier.py:24-47): out[0 .. L/2] = Re X_k, out[L/2+1 ..] = Im X_k for
 // k = 1 .. ceil(L/2)-1; scale 1/sqrt(L) both ways.
+//
+// Power-of-two lengths (the config-5 shard, L = 512) take the k_rfft_pow2 path further down: a REAL transform
+// as a half-length complex FFT plus a split pass, whole radix-8/4/2 butterflies in registers, float4 slab I/O.
 #include <math.h>
 
 #include <algorithm>
@@ -75,7 +78,9 @@ __device__ __forceinline__ float2* stockham(float2* x, float2* y, const float2* 
 template <bool INVERSE>
 __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float* __restrict__ out,
                                              const float2* __restrict__ Wg, FftPlan plan, int L, int C, int CG,
-                                             float scale) {
+                                             float scale, const float* __restrict__ a0,
+                                             const float* __restrict__ a1) {
+  // a0 / a1: the optional affine wrappers of k_rfft_pow2 (forward: (X - a0) / a1; inverse: x * a0 + a1 on the input)
   extern __shared__ __align__(16) float2 sm[];
   float2* W = sm;               // L twiddles
   float2* bufA = sm + L;        // L * CG
@@ -102,9 +107,15 @@ __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float
     for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
       int k = idx / cg, cc = idx - k * cg;
       int kk = (k < n_re) ? k : L - k;  // source harmonic
-      float re = src[(size_t)kk * C + c0 + cc];
+      const size_t gr = (size_t)kk * C + c0 + cc;
+      float re = src[gr];
+      if (a0) re = __fadd_rn(__fmul_rn(re, a0[gr]), a1[gr]);
       float im = 0.f;
-      if (kk >= 1 && kk <= L - n_re) im = src[(size_t)(n_re + kk - 1) * C + c0 + cc];
+      if (kk >= 1 && kk <= L - n_re) {
+        const size_t gi = (size_t)(n_re + kk - 1) * C + c0 + cc;
+        im = src[gi];
+        if (a0) im = __fadd_rn(__fmul_rn(im, a0[gi]), a1[gi]);
+      }
       if (k >= n_re) im = -im;
       bufA[k * CG + cc] = make_float2(re, im);
     }
@@ -119,7 +130,10 @@ __global__ __launch_bounds__(256) void k_fft(const float* __restrict__ in, float
       float v;
       if (o < n_re) v = x[o * CG + cc].x;
       else v = x[(o - n_re + 1) * CG + cc].y;
-      dst[(size_t)o * C + c0 + cc] = v * scale;
+      const size_t go = (size_t)o * C + c0 + cc;
+      v *= scale;
+      if (a0) v = __fdiv_rn(__fsub_rn(v, a0[go]), a1[go]);
+      dst[go] = v;
     }
   } else {
     for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
@@ -230,6 +244,385 @@ __global__ __launch_bounds__(256) void k_fresca_apply(const float* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Power-of-two lengths: real transform = complex FFT of half the length + split pass.
+//
+//   z[n] = x[2n] + i x[2n+1]  (n < N = L/2);  Z = FFT_N(z);  with W = exp(-2 pi i / L):
+//   forward  X[k]   = E + W^k D,  X[N-k] = conj(E - W^k D),  E = (Z[k] + conj Z[N-k]) / 2,  D = (Z[k] - conj Z[N-k]) / 2i
+//   inverse  Z[k]   = S + i Q,    Z[N-k] = conj(S - i Q),    S = X[k] + conj X[N-k],  Q = conj(W^k) (X[k] - conj X[N-k])
+// One workgroup owns one sample's (L x CG) slab.  LDS holds the length-L twiddle table and two N x CG complex
+// buffers; the second doubles as the (L x CG) real staging image of the packed spectrum, so that every HBM access
+// is a flat float4 copy of the slab (VEC: CG == C, C % 4 == 0) and half the LDS / flops of the full complex
+// transform are spent.  The Stockham passes keep one whole radix-8 / 4 / 2 butterfly per thread in registers
+// (R reads, R-1 twiddles, R writes per butterfly); the channel index is the fastest thread index, rounded up to a
+// power of two so that every index split is a shift.
+// ---------------------------------------------------------------------------
+struct Pow2Plan {
+  int npass;
+  int radix[12];
+};
+
+template <bool INV>
+__device__ __forceinline__ float2 mul_mi(float2 a) {  // a * (-i) forward, a * (+i) inverse
+  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& v0, float2& v1, float2& v2, float2& v3) {
+  const float2 s0 = cadd(v0, v2), d0 = csub(v0, v2), s1 = cadd(v1, v3), d1 = mul_mi<INV>(csub(v1, v3));
+  v0 = cadd(s0, s1), v2 = csub(s0, s1), v1 = cadd(d0, d1), v3 = csub(d0, d1);
+}
+
+template <int R, bool INV>
+__device__ __forceinline__ void dft_r(float2 (&v)[R]) {
+  if constexpr (R == 2) {
+    const float2 t = csub(v[0], v[1]);
+    v[0] = cadd(v[0], v[1]), v[1] = t;
+  } else if constexpr (R == 4) {
+    dft4<INV>(v[0], v[1], v[2], v[3]);
+  } else {
+    static_assert(R == 8, "radix 2, 4 or 8");
+    dft4<INV>(v[0], v[2], v[4], v[6]);  // even inputs -> E[0..3] in v[0], v[2], v[4], v[6]
+    dft4<INV>(v[1], v[3], v[5], v[7]);  // odd inputs  -> O[0..3] in v[1], v[3], v[5], v[7]
+    constexpr float h = 0.70710678118654752440f;
+    // w8^k O[k]:  w8 = exp(-+ i pi / 4)
+    const float2 o0 = v[1];
+    const float2 o1 = INV ? make_float2(h * (v[3].x - v[3].y), h * (v[3].x + v[3].y))
+                          : make_float2(h * (v[3].x + v[3].y), h * (v[3].y - v[3].x));
+    const float2 o2 = mul_mi<INV>(v[5]);
+    const float2 o3 = INV ? make_float2(-h * (v[7].x + v[7].y), h * (v[7].x - v[7].y))
+                          : make_float2(h * (v[7].y - v[7].x), -h * (v[7].x + v[7].y));
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    v[0] = cadd(e0, o0), v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1), v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2), v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3), v[7] = csub(e3, o3);
+  }
+}
+
+// One Stockham pass of radix R over the N-point transforms of cg channels: sub-length n = R m, stride s (n s = N).
+//   y[q + s (R p + k)] = w_n^{p k} sum_j x[q + s (p + j m)] w_R^{j k},   w_n^{pk} = T[2 p k s]   (T: length L = 2N)
+template <int R, bool INV>
+__device__ __forceinline__ void pow2_pass(const float2* __restrict__ x, float2* __restrict__ y,
+                                          const float2* __restrict__ T, int N, int ls, int lm, int CG, int cg, int lc) {
+  const int nb = (N / R) << lc;
+  const int s = 1 << ls, m = 1 << lm;
+  for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+    const int c = t & ((1 << lc) - 1);
+    if (c >= cg) continue;
+    const int jb = t >> lc;
+    const int q = jb & (s - 1), p = jb >> ls;
+    float2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = x[(q + s * (p + j * m)) * CG + c];
+    dft_r<R, INV>(v);
+    if (m > 1) {  // the last pass (m == 1, p == 0) has unit twiddles
+      const int e = p << (ls + 1);
+#pragma unroll
+      for (int k = 1; k < R; ++k) {
+        float2 w = T[e * k];
+        if (INV) w.y = -w.y;
+        v[k] = cmul(v[k], w);
+      }
+    }
+    float2* yo = y + (q + s * R * p) * CG + c;
+#pragma unroll
+    for (int k = 0; k < R; ++k) yo[s * k * CG] = v[k];
+  }
+  __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ float2* pow2_fft(float2* x, float2* y, const float2* T, const Pow2Plan& plan, int N, int CG,
+                                            int cg, int lc) {
+  int ls = 0, lm = 31 - __builtin_clz(N);
+  for (int ps = 0; ps < plan.npass; ++ps) {
+    const int R = plan.radix[ps];
+    const int lr = R == 8 ? 3 : (R == 4 ? 2 : 1);
+    lm -= lr;
+    if (R == 8) pow2_pass<8, INV>(x, y, T, N, ls, lm, CG, cg, lc);
+    else if (R == 4) pow2_pass<4, INV>(x, y, T, N, ls, lm, CG, cg, lc);
+    else pow2_pass<2, INV>(x, y, T, N, ls, lm, CG, cg, lc);
+    ls += lr;
+    float2* tmp = x;
+    x = y;
+    y = tmp;
+  }
+  return x;
+}
+
+// Z (N x CG complex) -> packed ortho spectrum rows (L x CG floats) in `st`, scaled by sc.
+__device__ __forceinline__ void pow2_split_fwd(const float2* __restrict__ Z, float* __restrict__ st,
+                                               const float2* __restrict__ T, int N, int CG, int cg, int lc, float sc) {
+  const int nk = ((N >> 1) + 1) << lc;
+  for (int t = threadIdx.x; t < nk; t += blockDim.x) {
+    const int c = t & ((1 << lc) - 1);
+    if (c >= cg) continue;
+    const int k = t >> lc;
+    if (k == 0) {
+      const float2 a = Z[c];
+      st[c] = (a.x + a.y) * sc;
+      st[N * CG + c] = (a.x - a.y) * sc;
+    } else {
+      const float2 A = Z[k * CG + c], B = Z[(N - k) * CG + c];
+      const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
+      const float2 D = make_float2(0.5f * (A.y + B.y), -0.5f * (A.x - B.x));  // (A - conj B) / 2i
+      const float2 P = cmul(T[k], D);
+      st[k * CG + c] = (E.x + P.x) * sc;
+      st[(N + k) * CG + c] = (E.y + P.y) * sc;
+      if (k != N - k) {
+        st[(N - k) * CG + c] = (E.x - P.x) * sc;
+        st[(2 * N - k) * CG + c] = -(E.y - P.y) * sc;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// packed spectrum rows (L x CG floats) in `st` -> Z (N x CG complex), unnormalised
+__device__ __forceinline__ void pow2_split_inv(const float* __restrict__ st, float2* __restrict__ Z,
+                                               const float2* __restrict__ T, int N, int CG, int cg, int lc) {
+  const int nk = ((N >> 1) + 1) << lc;
+  for (int t = threadIdx.x; t < nk; t += blockDim.x) {
+    const int c = t & ((1 << lc) - 1);
+    if (c >= cg) continue;
+    const int k = t >> lc;
+    if (k == 0) {
+      const float r0 = st[c], rn = st[N * CG + c];
+      Z[c] = make_float2(r0 + rn, r0 - rn);
+    } else {
+      const float2 X = make_float2(st[k * CG + c], st[(N + k) * CG + c]);
+      const float2 Y = (k != N - k) ? make_float2(st[(N - k) * CG + c], st[(2 * N - k) * CG + c]) : X;  // X[N-k]
+      const float2 S = make_float2(X.x + Y.x, X.y - Y.y);    // X[k] + conj X[N-k]
+      const float2 Dd = make_float2(X.x - Y.x, X.y + Y.y);   // X[k] - conj X[N-k]
+      float2 w = T[k];
+      w.y = -w.y;
+      const float2 Q = cmul(w, Dd);
+      Z[k * CG + c] = make_float2(S.x - Q.y, S.y + Q.x);                       // S + iQ
+      if (k != N - k) Z[(N - k) * CG + c] = make_float2(S.x + Q.y, -(S.y - Q.x));  // conj(S - iQ)
+    }
+  }
+  __syncthreads();
+}
+
+// slab (L x C) of one sample -> z image (even rows real parts, odd rows imaginary parts)
+template <bool VEC>
+__device__ __forceinline__ void pow2_load_time(const float* __restrict__ src, float2* __restrict__ z, int L, int C,
+                                               int c0, int CG, int cg) {
+  float* zf = reinterpret_cast<float*>(z);
+  if (VEC) {
+    const int C4 = C >> 2, n4 = L * C4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+      const float4 v = s4[f];
+      const int l = f / C4, cq = (f - l * C4) << 2;
+      float* d = zf + (((l >> 1) * CG + cq) << 1) + (l & 1);
+      d[0] = v.x, d[2] = v.y, d[4] = v.z, d[6] = v.w;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      const int l = idx / cg, cc = idx - l * cg;
+      zf[(((l >> 1) * CG + cc) << 1) + (l & 1)] = src[(size_t)l * C + c0 + cc];
+    }
+  }
+  __syncthreads();
+}
+
+// z image -> slab (L x C), scaled
+template <bool VEC>
+__device__ __forceinline__ void pow2_store_time(const float2* __restrict__ z, float* __restrict__ dst, int L, int C,
+                                                int c0, int CG, int cg, float sc) {
+  const float* zf = reinterpret_cast<const float*>(z);
+  if (VEC) {
+    const int C4 = C >> 2, n4 = L * C4;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+      const int l = f / C4, cq = (f - l * C4) << 2;
+      const float* p = zf + (((l >> 1) * CG + cq) << 1) + (l & 1);
+      d4[f] = make_float4(p[0] * sc, p[2] * sc, p[4] * sc, p[6] * sc);
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+      const int l = idx / cg, cc = idx - l * cg;
+      dst[(size_t)l * C + c0 + cc] = zf[(((l >> 1) * CG + cc) << 1) + (l & 1)] * sc;
+    }
+  }
+}
+
+// dft (INVERSE = false) / idft (true) of one sample slab per workgroup, with the optional affine wrappers:
+//   forward : out = (dft(x) - a0) / a1                    (datamodules.py:42-43,61-62; a0 = mean, a1 = std, (L, C))
+//   inverse : out = idft(x * a0 + a1)                     (cmd/sample.py:107-113;     a0 = std,  a1 = mean)
+// each product / sum rounded separately like the reference's tensor ops.
+template <bool INVERSE, bool VEC>
+__global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in, float* __restrict__ out,
+                                                   const float2* __restrict__ Wg, Pow2Plan plan, int L, int C, int CG,
+                                                   int lc, float scale, const float* __restrict__ a0,
+                                                   const float* __restrict__ a1) {
+  extern __shared__ __align__(16) float2 sm[];
+  const int N = L >> 1;
+  float2* T = sm;                 // L twiddles
+  float2* bufA = sm + L;          // N * CG complex
+  float2* bufB = bufA + N * CG;   // N * CG complex == L * CG floats
+  const int b = blockIdx.x;
+  const int c0 = blockIdx.y * CG;
+  const int cg = min(CG, C - c0);
+  const float* src = in + (size_t)b * L * C;
+  float* dst = out + (size_t)b * L * C;
+  for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
+  if (!INVERSE) {
+    pow2_load_time<VEC>(src, bufA, L, C, c0, CG, cg);  // (barrier inside; also covers the twiddle table)
+    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+    float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
+    pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+    if (VEC) {
+      const int n4 = (L * C) >> 2;
+      const float4* s4 = reinterpret_cast<const float4*>(st);
+      float4* d4 = reinterpret_cast<float4*>(dst);
+      for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+        float4 v = s4[f];
+        if (a0) {
+          const float4 mu = reinterpret_cast<const float4*>(a0)[f], sd = reinterpret_cast<const float4*>(a1)[f];
+          v = make_float4(__fdiv_rn(__fsub_rn(v.x, mu.x), sd.x), __fdiv_rn(__fsub_rn(v.y, mu.y), sd.y),
+                          __fdiv_rn(__fsub_rn(v.z, mu.z), sd.z), __fdiv_rn(__fsub_rn(v.w, mu.w), sd.w));
+        }
+        d4[f] = v;
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+        const int o = idx / cg, cc = idx - o * cg;
+        float v = st[o * CG + cc];
+        const size_t gi = (size_t)o * C + c0 + cc;
+        if (a0) v = __fdiv_rn(__fsub_rn(v, a0[gi]), a1[gi]);
+        dst[gi] = v;
+      }
+    }
+  } else {
+    float* st = reinterpret_cast<float*>(bufB);
+    if (VEC) {
+      const int n4 = (L * C) >> 2;
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+        float4 v = s4[f];
+        if (a0) {
+          const float4 sd = reinterpret_cast<const float4*>(a0)[f], mu = reinterpret_cast<const float4*>(a1)[f];
+          v = make_float4(__fadd_rn(__fmul_rn(v.x, sd.x), mu.x), __fadd_rn(__fmul_rn(v.y, sd.y), mu.y),
+                          __fadd_rn(__fmul_rn(v.z, sd.z), mu.z), __fadd_rn(__fmul_rn(v.w, sd.w), mu.w));
+        }
+        reinterpret_cast<float4*>(st)[f] = v;
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+        const int o = idx / cg, cc = idx - o * cg;
+        const size_t gi = (size_t)o * C + c0 + cc;
+        float v = src[gi];
+        if (a0) v = __fadd_rn(__fmul_rn(v, a0[gi]), a1[gi]);
+        st[o * CG + cc] = v;
+      }
+    }
+    __syncthreads();
+    pow2_split_inv(st, bufA, T, N, CG, cg, lc);
+    float2* z = pow2_fft<true>(bufA, bufB, T, plan, N, CG, cg, lc);
+    pow2_store_time<VEC>(z, dst, L, C, c0, CG, cg, scale);
+  }
+}
+
+// FreSca on the power-of-two path: per-sample |X_k| partial sums, and FFT -> per-bin scale -> inverse FFT.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_fresca_spectrum_pow2(const float* __restrict__ in, float* __restrict__ partial,
+                                                              const float2* __restrict__ Wg, Pow2Plan plan, int L, int C,
+                                                              int CG, int lc, float scale) {
+  extern __shared__ __align__(16) float2 sm[];
+  const int N = L >> 1;
+  float2* T = sm;
+  float2* bufA = sm + L;
+  float2* bufB = bufA + N * CG;
+  const int b = blockIdx.x, c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
+  pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg);
+  float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+  float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
+  pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+  const int nf = N + 1;
+  for (int k = threadIdx.x; k < nf; k += blockDim.x) {
+    const bool has_im = k >= 1 && k < N;
+    float acc = 0.f;
+    for (int c = 0; c < cg; ++c) {
+      const float re = st[k * CG + c], im = has_im ? st[(N + k) * CG + c] : 0.f;
+      acc += sqrtf(fmaf(re, re, im * im));
+    }
+    partial[((size_t)b * gridDim.y + blockIdx.y) * nf + k] = acc;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restrict__ in, float* __restrict__ out,
+                                                           const float2* __restrict__ Wg, Pow2Plan plan, int L, int C,
+                                                           int CG, int lc, const int* __restrict__ rc_dev, float rc_host,
+                                                           float low, float high, float scale) {
+  extern __shared__ __align__(16) float2 sm[];
+  const int N = L >> 1;
+  float2* T = sm;
+  float2* bufA = sm + L;
+  float2* bufB = bufA + N * CG;
+  const int b = blockIdx.x, c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
+  pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg);
+  float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+  float2* other = (Z == bufA) ? bufB : bufA;
+  float* st = reinterpret_cast<float*>(other);
+  pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+  // low-pass set: k <= Rc (energy: integer index from the cutoff kernel; spatial: Rc = r0 * n_freq)
+  const float rc = rc_dev ? (float)(*rc_dev) : rc_host;
+  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+    const int r = idx / cg, cc = idx - r * cg;
+    const int k = r <= N ? r : r - N;  // rows N+1.. hold Im X_k, k = r - N
+    st[r * CG + cc] *= ((float)k <= rc) ? low : high;
+  }
+  __syncthreads();
+  pow2_split_inv(st, Z, T, N, CG, cg, lc);
+  float2* z = pow2_fft<true>(Z, other, T, plan, N, CG, cg, lc);
+  pow2_store_time<VEC>(z, out + (size_t)b * L * C, L, C, c0, CG, cg, scale);
+}
+
+static bool is_pow2(int L) { return L >= 2 && (L & (L - 1)) == 0; }
+
+static Pow2Plan make_pow2_plan(int N) {  // radices of the N-point complex transform, N = 2^e; radix 8 last
+  Pow2Plan p{};
+  int e = 0;
+  while ((1 << e) < N) ++e;
+  const int r = e % 3;
+  if (r == 1 && e >= 4) p.radix[p.npass++] = 4, p.radix[p.npass++] = 4, e -= 4;
+  else if (r == 1) p.radix[p.npass++] = 2, e -= 1;
+  else if (r == 2) p.radix[p.npass++] = 4, e -= 2;
+  for (; e > 0; e -= 3) p.radix[p.npass++] = 8;
+  return p;
+}
+
+// channels per workgroup and LDS bytes of the power-of-two path: the whole slab when it fits
+// (<= 64 KiB keeps several workgroups on a CU; up to the CU's 160 KiB before the channels are split)
+static size_t pow2_lds(int L, int CG) { return (size_t)(L + (size_t)L * CG) * sizeof(float2); }
+static int pow2_cg(int L, int C) {
+  const size_t cap = 160 * 1024;
+  if (pow2_lds(L, C) <= cap) return C;
+  int CG = C;
+  while (CG > 1 && pow2_lds(L, CG) > 64 * 1024) CG = (CG + 1) / 2;
+  return CG;
+}
+static int ceil_log2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t lds) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
 static FftPlan make_plan(int L);
 
 static FftPlan make_plan(int L) {
@@ -280,25 +673,100 @@ static hipError_t get_twiddles(int L, const float2** out) {
   return hipSuccess;
 }
 
-hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s) {
+hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, const float* a0, const float* a1,
+                      hipStream_t s) {
   if (B <= 0) return hipSuccess;
   if (L < 1 || C < 1 || L > 8192) return hipErrorInvalidValue;
+  if ((a0 == nullptr) != (a1 == nullptr)) return hipErrorInvalidValue;
   const float2* W = nullptr;
   hipError_t e = get_twiddles(L, &W);
   if (e != hipSuccess) return e;
+  const float scale = (float)(1.0 / sqrt((double)L));
+  if (is_pow2(L)) {
+    const Pow2Plan plan = make_pow2_plan(L / 2);
+    const int CG = pow2_cg(L, C);
+    const size_t lds = pow2_lds(L, CG);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int lc = ceil_log2(CG);
+    const bool vec = CG == C && C % 4 == 0 && aligned16(in) && aligned16(out) && aligned16(a0) && aligned16(a1);
+    dim3 grid(B, cdiv(C, CG)), block(256);
+#define FFD_RFFT(INV, VEC)                                                                                   \
+  do {                                                                                                       \
+    if ((e = allow_lds(k_rfft_pow2<INV, VEC>, lds)) != hipSuccess) return e;                                 \
+    hipLaunchKernelGGL((k_rfft_pow2<INV, VEC>), grid, block, lds, s, in, out, W, plan, L, C, CG, lc, scale, a0, a1); \
+  } while (0)
+    if (inverse) {
+      if (vec) FFD_RFFT(true, true); else FFD_RFFT(true, false);
+    } else {
+      if (vec) FFD_RFFT(false, true); else FFD_RFFT(false, false);
+    }
+#undef FFD_RFFT
+    return hipGetLastError();
+  }
   FftPlan plan = make_plan(L);
   if (plan.npass > 16) return hipErrorInvalidValue;
   // channels per workgroup so that twiddles + two slabs fit in 64 KiB of LDS
   int CG = C;
   while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
   size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
   dim3 grid(B, cdiv(C, CG)), block(256);
-  float scale = (float)(1.0 / sqrt((double)L));
-  if (inverse)
-    hipLaunchKernelGGL(k_fft<true>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
-  else
-    hipLaunchKernelGGL(k_fft<false>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale);
+  if (inverse) {
+    if ((e = allow_lds(k_fft<true>, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fft<true>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale, a0, a1);
+  } else {
+    if ((e = allow_lds(k_fft<false>, lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fft<false>, grid, block, lds, s, in, out, W, plan, L, C, CG, scale, a0, a1);
+  }
+  return hipGetLastError();
+}
+
+// geometry shared by the FreSca / decomposition launchers
+struct SlabGeom {
+  bool pow2;
+  int CG, lc;
+  size_t lds;
+  FftPlan plan;
+  Pow2Plan plan2;
+};
+static hipError_t slab_geom(int L, int C, SlabGeom* g) {
+  g->pow2 = is_pow2(L);
+  if (g->pow2) {
+    g->plan2 = make_pow2_plan(L / 2);
+    g->CG = pow2_cg(L, C);
+    g->lds = pow2_lds(L, g->CG);
+    g->lc = ceil_log2(g->CG);
+  } else {
+    g->plan = make_plan(L);
+    int CG = C;
+    while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
+    g->CG = CG;
+    g->lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
+    g->lc = 0;
+  }
+  return g->lds > 160 * 1024 ? hipErrorInvalidValue : hipSuccess;
+}
+
+static hipError_t launch_fresca_apply(const float* in, float* out, const float2* W, const SlabGeom& g, int B, int L, int C,
+                                      const int* rc_dev, float rc_host, float low, float high, float sc, hipStream_t s) {
+  dim3 grid(B, cdiv(C, g.CG)), block(256);
+  hipError_t e;
+  if (g.pow2) {
+    const bool vec = g.CG == C && C % 4 == 0 && aligned16(in) && aligned16(out);
+    if (vec) {
+      if ((e = allow_lds(k_fresca_apply_pow2<true>, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_fresca_apply_pow2<true>, grid, block, g.lds, s, in, out, W, g.plan2, L, C, g.CG, g.lc, rc_dev,
+                         rc_host, low, high, sc);
+    } else {
+      if ((e = allow_lds(k_fresca_apply_pow2<false>, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_fresca_apply_pow2<false>, grid, block, g.lds, s, in, out, W, g.plan2, L, C, g.CG, g.lc, rc_dev,
+                         rc_host, low, high, sc);
+    }
+  } else {
+    if ((e = allow_lds(k_fresca_apply, g.lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fresca_apply, grid, block, g.lds, s, in, out, W, g.plan, L, C, g.CG, rc_dev, rc_host, low, high,
+                       sc * sc);
+  }
   return hipGetLastError();
 }
 
@@ -309,12 +777,9 @@ hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L,
   const float2* W = nullptr;
   hipError_t e = get_twiddles(L, &W);
   if (e != hipSuccess) return e;
-  FftPlan plan = make_plan(L);
-  int CG = C;
-  while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
-  const size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
-  const int NGc = cdiv(C, CG);
+  SlabGeom g;
+  if ((e = slab_geom(L, C, &g)) != hipSuccess) return e;
+  const int NGc = cdiv(C, g.CG);
   const int nf = L / 2 + 1;
   const float sc = (float)(1.0 / sqrt((double)L));
   const int* rc_dev = nullptr;
@@ -322,16 +787,26 @@ hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L,
   if (strategy == 1) {  // energy (fresca.py:46-58)
     float* partial = work;
     int* rc = reinterpret_cast<int*>(work + (size_t)B * NGc * nf);
-    hipLaunchKernelGGL(k_fresca_spectrum, dim3(B, NGc), dim3(256), lds, s, in, partial, W, plan, L, C, CG, sc);
+    dim3 grid(B, NGc), block(256);
+    if (g.pow2) {
+      if (g.CG == C && C % 4 == 0 && aligned16(in)) {
+        if ((e = allow_lds(k_fresca_spectrum_pow2<true>, g.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fresca_spectrum_pow2<true>, grid, block, g.lds, s, in, partial, W, g.plan2, L, C, g.CG, g.lc, sc);
+      } else {
+        if ((e = allow_lds(k_fresca_spectrum_pow2<false>, g.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fresca_spectrum_pow2<false>, grid, block, g.lds, s, in, partial, W, g.plan2, L, C, g.CG, g.lc, sc);
+      }
+    } else {
+      if ((e = allow_lds(k_fresca_spectrum, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL(k_fresca_spectrum, grid, block, g.lds, s, in, partial, W, g.plan, L, C, g.CG, sc);
+    }
     hipLaunchKernelGGL(k_fresca_cutoff, dim3(1), dim3(256), nf * sizeof(float), s, partial, rc, B, B * NGc, nf, C,
                        cutoff_ratio);
     rc_dev = rc;
   } else {  // spatial (fresca.py:40-43): Rc = r0 * n_freq, compared in fp32 like the reference's k tensor
     rc_host = (float)(cutoff_ratio * (double)nf);
   }
-  hipLaunchKernelGGL(k_fresca_apply, dim3(B, NGc), dim3(256), lds, s, in, out, W, plan, L, C, CG, rc_dev, rc_host, low,
-                     high, sc * sc);
-  return hipGetLastError();
+  return launch_fresca_apply(in, out, W, g, B, L, C, rc_dev, rc_host, low, high, sc, s);
 }
 
 // frequency_decompose_fft (fourier.py:219-286): rfft along L, keep bins k < n_low for the low part and
@@ -344,22 +819,15 @@ hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B
   const float2* W = nullptr;
   hipError_t e = get_twiddles(L, &W);
   if (e != hipSuccess) return e;
-  FftPlan plan = make_plan(L);
-  int CG = D;
-  while (CG > 1 && (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2) > 64 * 1024) CG = (CG + 1) / 2;
-  const size_t lds = (size_t)(L + 2 * (size_t)L * CG) * sizeof(float2);
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  SlabGeom g;
+  if ((e = slab_geom(L, D, &g)) != hipSuccess) return e;
   const int nf = L / 2 + 1;
   int n_low = (int)((double)nf * low_freq_ratio);  // fourier.py:249  max(1, int(n_freq * ratio))
   if (n_low < 1) n_low = 1;
   const float rc = (float)n_low - 0.5f;             // bins k <= rc  <=>  k < n_low
   const float sc = (float)(1.0 / sqrt((double)L));
-  dim3 grid(B, cdiv(D, CG)), block(256);
-  hipLaunchKernelGGL(k_fresca_apply, grid, block, lds, s, in, low, W, plan, L, D, CG, (const int*)nullptr, rc, 1.f, 0.f,
-                     sc * sc);
-  hipLaunchKernelGGL(k_fresca_apply, grid, block, lds, s, in, high, W, plan, L, D, CG, (const int*)nullptr, rc, 0.f, 1.f,
-                     sc * sc);
-  return hipGetLastError();
+  if ((e = launch_fresca_apply(in, low, W, g, B, L, D, nullptr, rc, 1.f, 0.f, sc, s)) != hipSuccess) return e;
+  return launch_fresca_apply(in, high, W, g, B, L, D, nullptr, rc, 0.f, 1.f, sc, s);
 }
 
 // spectral_density on a packed spectrum (fourier.py:111-130): |X_k|^2 for k = 0..L/2; the imaginary part of

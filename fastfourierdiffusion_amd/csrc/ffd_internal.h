@@ -97,6 +97,11 @@ struct SdeParams {
 };
 hipError_t launch_sde_step(float* x, const float* score, const float* z, const float* G, SdeParams p, uint64_t seed,
                            uint64_t elem_offset, uint32_t step, int B, int L, int C, hipStream_t s);
+// the two fused: x <- step(x, unembed(h)); the score stays in registers.  Needs unembed_sde_supported(C, D).
+bool unembed_sde_supported(int C, int D);
+hipError_t launch_unembed_sde(const float* h, const float* Wu, const float* bu, float* x, const float* z, const float* G,
+                              SdeParams p, uint64_t seed, uint64_t elem_offset, uint32_t step, int B, int L, int C,
+                              int D, hipStream_t s);
 hipError_t launch_prior(float* x, const float* z, const float* G, float scale, uint64_t seed, uint64_t elem_offset,
                         int B, int L, int C, hipStream_t s);
 
@@ -143,10 +148,17 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 // crf[l][:] <- h[l][:] for sample 0 is a plain D2D copy (done with hipMemcpyAsync)
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
+// large batches: input gates + recurrence of one residual LSTM layer in one launch (no gx tensor); in place on x
+bool lstm_mfma_selected(int B, int D);
+extern int g_lstm_mfma_min_batch;
+hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
+                            hipStream_t s);
 
 hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,
                         int M, int N, int K, int relu, hipStream_t s);
-hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, hipStream_t s);
+// a0 / a1 (both or neither; (L, C) on the device): forward out = (dft(in) - a0) / a1, inverse out = idft(in * a0 + a1)
+hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inverse, const float* a0, const float* a1,
+                      hipStream_t s);
 hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
                                  hipStream_t s);
 hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, int C, hipStream_t s);

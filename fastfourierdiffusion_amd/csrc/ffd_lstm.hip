@@ -183,6 +183,157 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
   }
 }
 
+// ---------------------------------------------------------------------------
+// Large batches: batch-tiled recurrence on the exact-fp32 matrix core, input gates fused.
+//
+// A workgroup (4 waves, one per SIMD) owns 16 S samples for the whole sequence.  Per cell step the gate
+// pre-activations of a 16-sample tile are  G^T (4d x 16) = W_ih x_t^T + W_hh h_{t-1}^T + b  on
+// v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand, resident in VGPRs for all L steps (each wave keeps the
+// fragments of its own 16-row tiles: 2 x 5 x 18 registers at d = 72), so neither W_ih nor W_hh is ever re-read and
+// the (B, L, 4d) gate tensor of the small-batch path (185 MB per 512 samples and layer) never exists.
+// Row order inside a 16-row tile is (unit, gate) = (i >> 2, i & 3): the accumulator D[i = 4 (l >> 4) + r][j = l & 15]
+// then leaves lane l with all FOUR gates (r = i, f, g, o) of unit 4 T + (l >> 4) for sample (l & 15) -- the cell update
+// is lane-local, c lives in a register, and the new h of unit 4 T + q sits in the lane that, as the B operand of
+// k-step s = T, must supply h[sample j][k = 4 s + q]: the same lane.  Waves own disjoint unit tiles, so h is exchanged
+// through a double-buffered LDS image (one barrier per cell step); x_t fragments come straight from global memory
+// (prefetched one step ahead; the four waves share the rows through L1) and double as the residual input.
+// 18 tiles over 4 waves split 5 / 5 / 4 / 4: the matrix pipe of the 5-tile SIMDs paces the step.
+// ---------------------------------------------------------------------------
+template <int D, int S>
+__global__ __launch_bounds__(256, 1) void k_lstm_mfma(float* __restrict__ x, const float* __restrict__ wih,
+                                                      const float* __restrict__ whh, const float* __restrict__ bsum,
+                                                      int B, int L) {
+  constexpr int NT = D / 4;          // unit tiles of 4 units x 4 gates == k-steps of 4
+  constexpr int NTW = (NT + 3) / 4;  // tiles per wave (upper bound)
+  constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
+  __shared__ float hbuf[2][S][16][HS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int t0 = wave * (NT / 4) + min(wave, NT % 4);
+  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);  // wave-uniform
+
+  // weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]) and biases (accumulator layout)
+  float wi[NTW][NT], wh[NTW][NT];
+  f32x4 bias[NTW];
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int T = min(t0 + tt, NT - 1);
+    const bool on = tt < ntw;
+    const size_t row = (size_t)((j & 3) * D + 4 * T + (j >> 2)) * D;
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+      wi[tt][s] = on ? wih[row + 4 * s + q] : 0.f;
+      wh[tt][s] = on ? whh[row + 4 * s + q] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * S * 16 * HS; i += blockDim.x) (&hbuf[0][0][0][0])[i] = 0.f;
+
+  const int b0 = blockIdx.x * (16 * S);
+  const float* xrow[S];
+  bool live[S];
+#pragma unroll
+  for (int ss = 0; ss < S; ++ss) {
+    const int b = b0 + 16 * ss + j;
+    live[ss] = b < B;
+    xrow[ss] = x + (size_t)min(b, B - 1) * L * D + q;
+  }
+  float c[NTW][S];
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+    for (int ss = 0; ss < S; ++ss) c[tt][ss] = 0.f;
+
+  float xb[S][NT], xn[S][NT];
+#pragma unroll
+  for (int ss = 0; ss < S; ++ss)
+#pragma unroll
+    for (int s = 0; s < NT; ++s) xb[ss][s] = xrow[ss][4 * s];
+  int cur = 0;
+  for (int t = 0; t < L; ++t) {
+    if (t + 1 < L) {
+#pragma unroll
+      for (int ss = 0; ss < S; ++ss)
+#pragma unroll
+        for (int s = 0; s < NT; ++s) xn[ss][s] = xrow[ss][(size_t)(t + 1) * D + 4 * s];
+    }
+    // input part (independent of h): acc = b + W_ih x_t
+    f32x4 acc[NTW][S];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+      for (int ss = 0; ss < S; ++ss) acc[tt][ss] = bias[tt];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        if (tt < ntw) {
+#pragma unroll
+          for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wi[tt][s], xb[ss][s], acc[tt][ss]);
+        }
+    __syncthreads();  // h_{t-1} of every wave is in hbuf[cur]
+    float hb[S][NT];
+#pragma unroll
+    for (int ss = 0; ss < S; ++ss)
+#pragma unroll
+      for (int s = 0; s < NT; ++s) hb[ss][s] = hbuf[cur][ss][j][4 * s + q];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        if (tt < ntw) {
+#pragma unroll
+          for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wh[tt][s], hb[ss][s], acc[tt][ss]);
+        }
+    // cell update, lane-local: (i, f, g, o) = acc[0..3] of unit 4 T + q, sample j
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) {
+        const int u = 4 * (t0 + tt) + q;
+#pragma unroll
+        for (int ss = 0; ss < S; ++ss) {
+          const f32x4 a = acc[tt][ss];
+          const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go = sigmoid_fast(a[3]);
+          c[tt][ss] = gf * c[tt][ss] + gi * gg;
+          const float h = go * tanh_fast(c[tt][ss]);
+          hbuf[cur ^ 1][ss][j][u] = h;
+          float xres = 0.f;  // x_t[u]: k-step s = t0 + tt of the lane's own fragment
+#pragma unroll
+          for (int s = 0; s < NT; ++s) xres = (s == t0 + tt) ? xb[ss][s] : xres;
+          if (live[ss]) const_cast<float*>(xrow[ss])[(size_t)t * D + 4 * (t0 + tt)] = xres + h;  // x <- x + LSTM(x)
+        }
+      }
+    cur ^= 1;
+#pragma unroll
+    for (int ss = 0; ss < S; ++ss)
+#pragma unroll
+      for (int s = 0; s < NT; ++s) xb[ss][s] = xn[ss][s];
+  }
+}
+
+// batch from which the batch-tiled kernel is faster than one sample per workgroup (measured crossover)
+int g_lstm_mfma_min_batch = 1536;
+
+bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
+
+hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
+                            hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  const bool two = B > 16 * 256;  // 32 samples per workgroup once 16-sample tiles exceed the CU count
+  switch (D) {
+#define X(d)                                                                                                          \
+  case d:                                                                                                             \
+    if (two) hipLaunchKernelGGL((k_lstm_mfma<d, 2>), dim3(cdiv(B, 32)), dim3(256), 0, s, x, wih, whh, bsum, B, L);     \
+    else hipLaunchKernelGGL((k_lstm_mfma<d, 1>), dim3(cdiv(B, 16)), dim3(256), 0, s, x, wih, whh, bsum, B, L);         \
+    break;
+    X(16) X(24) X(32) X(48) X(60) X(64) X(72)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s) {
   if (B <= 0) return hipSuccess;
   // two samples per workgroup while the W_hh row + chunk registers fit, one for d_model >= 64

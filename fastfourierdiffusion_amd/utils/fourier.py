@@ -46,6 +46,31 @@ def idft(x: torch.Tensor) -> torch.Tensor:
     return _run(x, inverse=True)
 
 
+def _run_affine(x: torch.Tensor, mean: torch.Tensor, std: torch.Tensor, inverse: bool) -> torch.Tensor:
+    assert x.dim() == 3, f"expected (batch_size, max_len, n_channels), got {tuple(x.shape)}"
+    src_device = x.device
+    xd = _on_gpu(x, "dft/idft")
+    B, L, Cn = xd.shape
+    mu = torch.broadcast_to(torch.as_tensor(mean, dtype=torch.float32), (L, Cn)).to(xd.device).contiguous()
+    sd = torch.broadcast_to(torch.as_tensor(std, dtype=torch.float32), (L, Cn)).to(xd.device).contiguous()
+    out = torch.empty_like(xd)
+    fn = N.lib().ffd_unstandardize_idft if inverse else N.lib().ffd_dft_standardize
+    N.check(fn(xd.data_ptr(), out.data_ptr(), mu.data_ptr(), sd.data_ptr(), B, L, Cn, N.current_stream_ptr(xd.device)),
+            None, "ffd_unstandardize_idft" if inverse else "ffd_dft_standardize")
+    return out.to(src_device) if src_device.type != "cuda" else out
+
+
+def unstandardize_idft(x: torch.Tensor, feature_mean: torch.Tensor, feature_std: torch.Tensor) -> torch.Tensor:
+    """The post-step of ``cmd/sample.py:107-113`` in one kernel: ``idft(X * feature_std + feature_mean)``
+    (samples drawn in the standardised frequency domain -> time series on the data's scale)."""
+    return _run_affine(x, feature_mean, feature_std, inverse=True)
+
+
+def dft_standardize(x: torch.Tensor, feature_mean: torch.Tensor, feature_std: torch.Tensor) -> torch.Tensor:
+    """The ingest twin, ``DiffusionDataset`` (datamodules.py:42-43,61-62): ``(dft(X) - feature_mean) / feature_std``."""
+    return _run_affine(x, feature_mean, feature_std, inverse=False)
+
+
 def _on_gpu(x: torch.Tensor, what: str) -> torch.Tensor:
     if x.device.type != "cuda":
         if not torch.cuda.is_available():

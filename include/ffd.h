@@ -173,6 +173,14 @@ int ffd_prior(const ffd_sde_desc* sde, float* x, const float* z, const float* G,
  * its inverse along dim 1 of (B,L,C).  `in` and `out` may not alias. Context-free. */
 int ffd_dft(const float* in, float* out, int B, int L, int C, void* stream);
 int ffd_idft(const float* in, float* out, int B, int L, int C, void* stream);
+/* The runner-side wrappers around them, fused into the same kernel (no extra pass over the data):
+ *   ffd_unstandardize_idft  cmd/sample.py:107-113   out = idft(in * std + mean)   (sampled spectra -> time series)
+ *   ffd_dft_standardize     src/fdiff/dataloaders/datamodules.py:42-43,61-62   out = (dft(in) - mean) / std
+ * mean / std: (L, C) fp32 on the device (DiffusionDataset.feature_mean / feature_std), broadcast over B. */
+int ffd_unstandardize_idft(const float* in, float* out, const float* mean, const float* std, int B, int L, int C,
+                           void* stream);
+int ffd_dft_standardize(const float* in, float* out, const float* mean, const float* std, int B, int L, int C,
+                        void* stream);
 
 /* PositionalEncoding.forward (transformer.py:17-29): out = x + weight[arange(L)] for x (B,L,D); like
  * nn.Embedding(max_norm) the looked-up rows of `weight` (L,D, device) are renormalised IN PLACE first
@@ -286,6 +294,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
  *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
+ *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
+ *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
  *   "fuse_layer" = -1 (auto) | 0 | 1           out-proj+LN1+FFN+LN2+next-QKV in one launch (k_layer; default 0);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;

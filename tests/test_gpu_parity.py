@@ -994,6 +994,84 @@ def test_kernel_timing_and_work_accounting(ffd):
     fl, by = C.c_double(), C.c_double()
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_ln"
     assert fl.value == 4.0 * 512 * L * d * F  # 56.47 GFLOP at the ECG bench shape
-    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)) is not None
-    assert by.value == 12.0 * 512 * L * Cn
+    # the sampling loop unembeds inside the step kernel: hidden row + x in, x out
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)).startswith(b"k_unembed_mfma")
+    assert by.value == 4.0 * 512 * L * (d + 2 * Cn)
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) is None
+
+
+@pytest.mark.parametrize("case", cases.AFFINE_FFT_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
+def test_affine_fft_golden(ffd, golden, case):
+    """cmd/sample.py:107-113 (X * std + mean, then idft) and datamodules.py:42-62 ((dft(X) - mean) / std), each
+    fused into the transform kernel; goldens from the reference's own tensor ops + dft / idft (g12)."""
+    from fastfourierdiffusion_amd.utils.fourier import dft, dft_standardize, idft, unstandardize_idft
+
+    L, C, B, seed = case
+    x, mean, std = (torch.from_numpy(a) for a in synthetic.noise_stream((B, L, C), 3, seed))
+    mean, std = mean[0], std[0].abs() + 0.5
+    g = golden["g12_round2"]
+    xs = unstandardize_idft(x.cuda(), mean, std)
+    assert xs.device.type == "cuda" and rel_err(xs.cpu(), g[f"unstd_idft_L{L}_C{C}"]) < TOL_OP
+    xf = dft_standardize(x, mean, std)  # host tensor in -> host tensor out, like dft / idft
+    assert xf.device.type == "cpu" and rel_err(xf, g[f"dft_std_L{L}_C{C}"]) < TOL_OP
+    # the fused forms equal the two-step forms bit for bit (same kernel, same rounding sequence as the reference's ops)
+    assert torch.equal(xs.cpu(), idft((x * std + mean).cuda()).cpu())
+    assert torch.equal(xf, (dft(x) - mean) / std)
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 1), (2, 4, 3), (5, 8, 8), (2, 16, 4), (3, 32, 5), (2, 64, 8), (2, 128, 1),
+                                   (3, 1024, 8), (2, 2048, 4), (1, 4096, 3), (2, 512, 72), (2, 256, 40)])
+def test_pow2_real_fft_paths_vs_oracle(ffd, shape):
+    """Power-of-two lengths run the half-length complex FFT + split kernel (k_rfft_pow2): every radix plan
+    (2 | 4 | 4,4 | 8 ... ), the float4 slab path (C % 4 == 0) and the scalar one, channel groups split over
+    workgroups when the slab exceeds the CU's LDS, plus FreSca / decomposition on the same path."""
+    from fastfourierdiffusion_amd.utils.fourier import dft, frequency_decompose_fft, idft
+    from fastfourierdiffusion_amd.utils.fresca import apply_fresca_to_score
+
+    B, L, C = shape
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 1000 + L + C)))
+    xf = dft(x.cuda())
+    assert rel_err(xf.cpu(), O.dft(x)) < TOL_OP
+    assert rel_err(idft(x.cuda()).cpu(), O.idft(x)) < TOL_OP
+    assert rel_err(idft(xf).cpu(), x) < 2 * TOL_OP
+    if L >= 4 and L <= 1024:
+        for strat in ("energy", "spatial"):
+            y = apply_fresca_to_score(x.cuda(), low_scale=0.9, high_scale=1.4, cutoff_ratio=0.45, cutoff_strategy=strat)
+            assert rel_err(y.cpu(), O.fresca(x, 0.9, 1.4, 0.45, strat, None, None)) < TOL_OP, strat
+        lo, hi = frequency_decompose_fft(x.cuda(), 0.3)
+        olo, ohi = O.frequency_decompose(x, 0.3)
+        assert rel_err(lo.cpu(), olo) < TOL_OP and rel_err(hi.cpu(), ohi) < TOL_OP
+
+
+@pytest.mark.parametrize("name", ["ecg", "small", "syn", "nasa_lstm"])
+def test_fused_unembed_sde_tail_equals_two_kernels(ffd, name):
+    """ffd_sample_batch unembeds inside the SDE-step kernel (k_unembed_mfma<D, true>): same MFMA sequence for the
+    score, same sde_update, same Philox indexing as unembed + k_sde_step -> bit-identical trajectories, with
+    on-device Philox noise and with injected draws, C = 1 / 3 / 4 / 8."""
+    import ctypes as C
+
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+    m, sch = make_model(ffd, c)
+    ctx = m._ctx()
+    B, L, Cn = 3, c["L"], c["C"]
+    sch.set_timesteps(20)
+    ts_c = (C.c_float * 20)(*sch.timesteps.tolist())
+    x0 = torch.from_numpy(next(synthetic.noise_stream((B, L, Cn), 1, 77))).cuda()
+    zs = torch.from_numpy(np.stack(list(synthetic.noise_stream((B, L, Cn), 4, 78)))).cuda()
+    s = N.current_stream_ptr(x0.device)
+    res = {}
+    try:
+        for fuse in (1, 0):
+            assert ctx.lib.ffd_tune(b"fuse_tail", fuse) == 0
+            for z in (None, zs):
+                x = x0.clone()
+                N.check(ctx.lib.ffd_sample_batch(ctx.handle, x.data_ptr(), B, ts_c, 20, float(sch.step_size), 2, 4, 9, 5,
+                                                 z.data_ptr() if z is not None else None, 0, 0, s), ctx.handle, "sample")
+                res[(fuse, z is None)] = x
+    finally:
+        ctx.lib.ffd_tune(b"fuse_tail", 1)
+    for philox in (True, False):
+        assert torch.isfinite(res[(1, philox)]).all()
+        assert torch.equal(res[(1, philox)], res[(0, philox)]), philox

@@ -40,8 +40,6 @@ for _ in range(iters):
 for i in range(iters):
     assert lib.ffd_sde_step(C.byref(sde), x.data_ptr(), y.data_ptr(), Gd.data_ptr(), 0.5, 1e-3, None, 42, 0, i, B, L, Cn, s) == 0
 for i in range(iters):
-    assert lib.ffd_sde_step(C.byref(sde), x.data_ptr(), y.data_ptr(), Gd.data_ptr(), 0.5, 1e-3, z.data_ptr(), 42, 0, i, B, L, Cn, s) == 0
-for i in range(iters):
     assert lib.ffd_prior(C.byref(sde), x.data_ptr(), None, Gd.data_ptr(), 42, 0, B, L, Cn, s) == 0
 for i in range(iters):
     assert lib.ffd_fresca(y.data_ptr(), x.data_ptr(), work.data_ptr(), B, L, Cn, 1.0, 1.5, 0.5, 0, s) == 0
@@ -66,9 +64,9 @@ N.check(lib.ffd_sample_batch(ctx.handle, xs.data_ptr(), Bs, ts_c, 1000, float(sc
 torch.cuda.synchronize()
 d = 72
 print(json.dumps({"B": B, "L": L, "C": Cn, "B_score": Bs, "algorithmic_bytes": {
-    "k_fft<false>": 8 * n, "k_fft<true>": 8 * n, "k_rfft": 8 * n, "k_irfft": 8 * n,
-    "k_sde_step": 12 * n, "k_sde_step(z)": 16 * n, "k_prior": 4 * n,
+    "k_fft<false>": 8 * n, "k_fft<true>": 8 * n, "k_rfft_pow2": 8 * n,
+    "k_sde_step": 12 * n, "k_prior": 4 * n,
     "k_fresca_apply": 8 * n, "k_fresca_spectrum": 4 * n,
-    "k_embed": 4 * Bs * L * (Cn + d), "k_unembed": 4 * Bs * L * (Cn + d),
-    "k_unembed_sde": 4 * Bs * L * (d + 2 * Cn),
+    "k_embed": 4 * Bs * L * (Cn + d), "k_unembed_mfma<72, false>": 4 * Bs * L * (Cn + d), "k_unembed(": 4 * Bs * L * (Cn + d),
+    "k_unembed_mfma<72, true>": 4 * Bs * L * (d + 2 * Cn),
     "k_linear_res_ln": 4 * Bs * L * 3 * d}}))

@@ -8,15 +8,13 @@ print("kernel,calls,avg_us,algorithmic_MB,GB_per_s,frac_of_8TBps")
 for r in csv.DictReader(open(f)):
     name = r["Name"]
     key = None
-    for k in by:
-        base = k.split("(")[0]
-        if base in name:
-            key = base if key is None or len(base) > len(key) else key
+    for k in by:  # longest matching key wins (k_fresca_apply also matches k_fresca_apply_pow2, ...)
+        if k in name and (key is None or len(k) > len(key)):
+            key = k
     if key is None:
         continue
     us = float(r["AverageNs"]) / 1e3
     b = by[key]
-    if key == "k_sde_step" and "k_unembed_sde" not in name:
-        b = by["k_sde_step"]  # mixed Philox / injected launches share one row: quote the 12 B/element figure
     gbs = b / (us * 1e-6) / 1e9
-    print(f"{name.split('(')[0][-48:]},{r['Calls']},{us:.1f},{b / 1e6:.1f},{gbs:.0f},{gbs / 8000:.3f}")
+    short = name.split("(")[0].replace("void ", "").replace("ffd::", "")
+    print(f"{short[:48]},{r['Calls']},{us:.1f},{b / 1e6:.1f},{gbs:.0f},{gbs / 8000:.3f}")
