@@ -64,7 +64,6 @@ SIGNATURES = {
     "ffd_hermite_predict": (C.c_int, [_P, C.POINTER(C.c_double), C.c_double, C.c_int, _P, C.c_int, C.c_size_t, _P]),
     "ffd_spectral_density": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_cache_crf_capture": (C.c_int, [_P, C.POINTER(CrfCaptureCfg)]),
-    "ffd_row_delta_norm_mean": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_double), _P]),
     "ffd_create": (C.c_int, [C.POINTER(_P), C.POINTER(ModelDesc), C.c_int]),
     "ffd_destroy": (None, [_P]),
     "ffd_last_error": (C.c_char_p, [_P]),
@@ -105,6 +104,7 @@ SIGNATURES = {
     "ffd_cache_configure": (C.c_int, [_P, C.POINTER(CacheCfg)]),
     "ffd_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
+    "ffd_probe_ffn_clock": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -64,6 +64,7 @@ struct ffd_ctx {
   // workspace
   int ws_B = 0;
   float *h0 = nullptr, *h1 = nullptr, *qkv = nullptr, *attn = nullptr, *score = nullptr;
+  size_t qkv_floats = 0;
   float *temb1 = nullptr, *temb_tab = nullptr, *ts_dev = nullptr;
   int temb_cap = 0;
   std::vector<float> ts_host;
@@ -119,7 +120,6 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
   return FFD_OK;
 }
 
-static int g_bench_kernel = 0;
 static int g_fuse_tail = 1;
 
 // HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
@@ -174,13 +174,13 @@ int ffd_tune(const char* key, int value) {
     g_ffn_stagger = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "ffn_rem")) {
-    g_ffn_rem = value ? 1 : 0;
+  if (!strcmp(key, "ffn_persist")) {  // 0: one workgroup per tile; n >= 1: persistent grid of n x the resident workgroups
+    if (value < 0 || value > 8) return FFD_ERR_INVALID;
+    g_ffn_persist = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "bench_kernel")) {  // what ffd_bench_ffn times: 0 k_ffn_ln, 1 k_layer, 2 k_layer + next QKV
-    if (value < 0 || value > 2) return FFD_ERR_INVALID;
-    g_bench_kernel = value;
+  if (!strcmp(key, "ffn_rem")) {
+    g_ffn_rem = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "lstm_mfma_min_batch")) {  // batch from which the batch-tiled MFMA recurrence is used
@@ -188,13 +188,13 @@ int ffd_tune(const char* key, int value) {
     g_lstm_mfma_min_batch = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "fuse_tail")) {  // unembed inside the SDE-step kernel of ffd_sample_batch
-    g_fuse_tail = value ? 1 : 0;
+  if (!strcmp(key, "lstm_mfma_s")) {  // 16-sample tiles per workgroup of that kernel (0 = by batch)
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_lstm_mfma_s = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "fuse_layer")) {
-    if (value < -1 || value > 1) return FFD_ERR_INVALID;
-    g_fuse_layer = value;
+  if (!strcmp(key, "fuse_tail")) {  // unembed inside the SDE-step kernel of ffd_sample_batch
+    g_fuse_tail = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "attn_qg")) {
@@ -210,11 +210,6 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "attn_fused")) {
     if (value < 0 || value > 1) return FFD_ERR_INVALID;
     g_attn_fused = value;
-    return FFD_OK;
-  }
-  if (!strcmp(key, "attn_impl")) {
-    if (value < 0 || value > 3) return FFD_ERR_INVALID;
-    g_attn_impl = value;
     return FFD_OK;
   }
   return FFD_ERR_INVALID;
@@ -515,14 +510,22 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   if (m.kind == FFD_MODEL_MLP) {
     if ((rc = dev_alloc(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
     if ((rc = dev_alloc(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
+    ctx->qkv_floats = (size_t)B * m.dim_feedforward;
   } else if (m.kind == FFD_MODEL_TRANSFORMER) {
     if ((rc = dev_alloc(ctx, &ctx->h1, M * d))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->qkv, M * 3 * d))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->attn, M * d))) return rc;
-  } else {
-    if ((rc = dev_alloc(ctx, &ctx->qkv, M * 4 * d))) return rc;  // gate pre-activations gx
   }
+  // (the head-major q/k/v regions of the two-kernel attention fallback and the LSTM gate pre-activations are
+  //  allocated on first use by ensure_qkv: the default paths never touch them -- 3.6 GB at B = 8192, L = 512)
   ctx->ws_B = B;
+  return FFD_OK;
+}
+
+static int ensure_qkv(ffd_ctx* ctx, size_t floats) {
+  if (floats <= ctx->qkv_floats) return FFD_OK;
+  int rc = dev_alloc(ctx, &ctx->qkv, floats);
+  if (rc) return rc;
+  ctx->qkv_floats = floats;
   return FFD_OK;
 }
 
@@ -566,6 +569,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
         TIMED(FFD_K_LSTM_REC, launch_lstm_mfma(ctx->h0, l.wih, l.whh, l.bsum, B, L, d, s));
         continue;
       }
+      if (int rc = ensure_qkv(ctx, (size_t)M * 4 * d)) return rc;  // gate pre-activations gx
       TIMED(FFD_K_LSTM_GATES, launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
       TIMED(FFD_K_LSTM_REC, launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
     }
@@ -589,19 +593,18 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
     else mode = MIXED;
   }
   const size_t lt = (size_t)H * L * hd;  // table floats per layer
-  // q / k / v regions, head-major (B,H,L,hd)
+  const int nreg = (mode == PURE) ? 1 : 3;
+  const int n_own = (mode == PURE) ? 0 : (mode == MIXED) ? n_rec : L;
+  const bool qkv_attn = g_attn_fused && ctx->packed[0].aw_full != nullptr;
+  // q / k / v regions, head-major (B,H,L,hd): only the two-kernel fallback uses them
+  if (!qkv_attn)
+    if (int rc = ensure_qkv(ctx, (size_t)M * 3 * d)) return rc;
   float* qreg = ctx->qkv;
   float* kreg = ctx->qkv + (size_t)M * d;
   float* vreg = ctx->qkv + 2 * (size_t)M * d;
-  const int nreg = (mode == PURE) ? 1 : 3;
-  const int n_own = (mode == PURE) ? 0 : (mode == MIXED) ? n_rec : L;
-  const bool fused = g_fuse_layer == 1 || (g_fuse_layer < 0 && cdiv(M, 64) >= 256);
-  const bool qkv_attn = !fused && g_attn_fused && ctx->packed[0].aw_full != nullptr;
   float* cur = ctx->h0;  // layer input / residual
   float* alt = ctx->h1;
   auto proj_w = [&](int i) { return mode == PURE ? ctx->packed[i].q_wp : ctx->packed[i].in_wp; };
-  if (fused)
-    HIPCHECK(launch_linear_hm(cur, proj_w(0), ctx->layers[0].in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
   for (int i = 0; i < m.num_layers; ++i) {
     const LayerWeights& w = ctx->layers[i];
     const LayerPacked& pk = ctx->packed[i];
@@ -617,28 +620,14 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
                                              tables ? vt : nullptr, mode == MIXED ? kt : nullptr,
                                              mode == MIXED ? vt : nullptr, ctx->attn, B, L, d, hd, n_own, s));
     } else {
-      if (!fused) HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
+      HIPCHECK(launch_linear_hm(cur, proj_w(i), w.in_b, qreg, kreg, vreg, M, nreg, d, L, H, hd, s));
       HIPCHECK(launch_attention(qreg, kreg, vreg, tables ? kt : nullptr, tables ? vt : nullptr, ctx->attn, B, L, H, hd,
                                 n_own, s));
       if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
         HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
     }
-    if (fused) {
-      NextProj nx{};
-      if (i + 1 < m.num_layers) {
-        nx.wp = proj_w(i + 1);
-        nx.bias = ctx->layers[i + 1].in_b;
-        nx.q = qreg, nx.k = kreg, nx.v = vreg;
-        nx.nreg = nreg, nx.L = L, nx.H = H, nx.hd = hd;
-      }
-      HIPCHECK(launch_layer(ctx->attn, cur, w, alt, nx, M, d, F, s));
-      float* t = cur;
-      cur = alt;
-      alt = t;
-    } else {
-      TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-      TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s));
-    }
+    TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+    TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s));
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
       // straight into this layer's tables: head-major (1,H,L,hd) == table layout
@@ -911,21 +900,6 @@ int ffd_hermite_predict(const float* history, const double* timesteps, double ta
     }
   }
   return launch_weighted_sum(history, w, out, K, n, (hipStream_t)stream) == hipSuccess ? FFD_OK : FFD_ERR_HIP;
-}
-
-int ffd_row_delta_norm_mean(const float* a, const float* b, float* work, int rows, int D, double* mean_out,
-                            void* stream) {
-  if (!a || !b || !work || !mean_out || rows < 1 || D < 1) return FFD_ERR_INVALID;
-  const int nblocks = std::min(256, cdiv(rows, 4));
-  hipStream_t s = (hipStream_t)stream;
-  if (launch_row_delta_norm(a, b, work, nblocks, rows, D, s) != hipSuccess) return FFD_ERR_HIP;
-  float part[256];
-  if (hipMemcpyAsync(part, work, sizeof(float) * nblocks, hipMemcpyDeviceToHost, s) != hipSuccess) return FFD_ERR_HIP;
-  if (hipStreamSynchronize(s) != hipSuccess) return FFD_ERR_HIP;
-  double tot = 0.0;
-  for (int i = 0; i < nblocks; ++i) tot += (double)part[i];
-  *mean_out = tot / (double)rows;
-  return FFD_OK;
 }
 
 int ffd_cache_crf_capture(ffd_ctx* ctx, const ffd_crf_capture_cfg* cfg) {
@@ -1241,18 +1215,7 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);
   HIPCHECK(hipGetLastError());
-  hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->attn, (size_t)M * d, 0x1234567u);
-  HIPCHECK(hipGetLastError());
-  NextProj nx{};
-  if (g_bench_kernel == 2 && m.num_layers > 1) {
-    nx.wp = ctx->packed[1].in_wp, nx.bias = ctx->layers[1].in_b;
-    nx.q = ctx->qkv, nx.k = ctx->qkv + (size_t)M * d, nx.v = ctx->qkv + 2 * (size_t)M * d;
-    nx.nreg = 3, nx.L = m.max_len, nx.H = m.n_head, nx.hd = d / m.n_head;
-  }
-  auto run = [&]() -> hipError_t {
-    if (g_bench_kernel == 0) return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s);
-    return launch_layer(ctx->attn, ctx->h1, ctx->layers[0], ctx->h0, nx, M, d, m.dim_feedforward, s);
-  };
+  auto run = [&]() -> hipError_t { return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s); };
   for (int i = 0; i < 3; ++i) HIPCHECK(run());
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
@@ -1266,6 +1229,59 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   *ms_out = ms / iters;
+  return FFD_OK;
+}
+
+int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out,
+                        void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  if (ctx->desc.kind != FFD_MODEL_TRANSFORMER) return ctx->fail(FFD_ERR_UNSUPPORTED, "no FFN in this backbone");
+  if (!ghz_out || !(warm_seconds >= 0.0) || warm_seconds > 30.0) return ctx->fail(FFD_ERR_INVALID, "bad argument");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  const ffd_model_desc& m = ctx->desc;
+  const int M = B * m.max_len, d = m.d_model;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);  // random data
+  HIPCHECK(hipGetLastError());
+  const int nwg = cdiv(M, ffn_tile_rows(M));
+  unsigned long long* stamps = nullptr;
+  HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * nwg));
+  HIPCHECK(hipMemsetAsync(stamps, 0, sizeof(unsigned long long) * 2 * nwg, s));
+  // back-to-back launches for warm_seconds (the clock the chip settles at under this load), then the stamped one
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  HIPCHECK(hipEventRecord(e0, s));
+  double elapsed = 0.0;
+  while (elapsed < warm_seconds) {
+    for (int i = 0; i < 50; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+    HIPCHECK(hipEventRecord(e1, s));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    elapsed = ms * 1e-3;
+  }
+  HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, stamps));
+  std::vector<unsigned long long> h(2 * (size_t)nwg);
+  HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 2 * nwg, hipMemcpyDeviceToHost, s));
+  HIPCHECK(hipStreamSynchronize(s));
+  (void)hipFree(stamps);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  std::vector<double> ghz, us;
+  for (int i = 0; i < nwg; ++i)
+    if (h[2 * i + 1] > 0) {
+      ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);  // shader cycles per 10 ns tick
+      us.push_back((double)h[2 * i + 1] * 0.01);
+    }
+  if (ghz.empty()) return ctx->fail(FFD_ERR_STATE, "no stamps were written");
+  std::sort(ghz.begin(), ghz.end());
+  std::sort(us.begin(), us.end());
+  *ghz_out = ghz[ghz.size() / 2];
+  if (loop_us_out) *loop_us_out = us[us.size() / 2];
   return FFD_OK;
 }
 

@@ -164,9 +164,9 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
   const float4 bias = *reinterpret_cast<const float4*>(be + j);
   unsigned b = row / (unsigned)L, l = row - b * (unsigned)L;
   const unsigned qb = rs / (unsigned)L, rl = rs - qb * (unsigned)L;
-  for (; row < M; row += rs) {
-    float xv[8];
-    const float* x = X + (size_t)row * C;
+  const float4 t0 = *reinterpret_cast<const float4*>(temb + j);  // the shared time embedding (temb_stride == 0)
+  auto load_x = [&](unsigned rw, float (&xv)[8]) {
+    const float* x = X + (size_t)rw * C;
     if (XVEC) {
       const float4 a = *reinterpret_cast<const float4*>(x);
       xv[0] = a.x, xv[1] = a.y, xv[2] = a.z, xv[3] = a.w;
@@ -178,18 +178,37 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
 #pragma unroll
       for (int c = 0; c < 8; ++c) xv[c] = c < C ? x[c] : 0.f;
     }
+  };
+  auto emit = [&](unsigned rw, unsigned bb, unsigned ll, const float (&xv)[8], float4 p) {
     float4 v = bias;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
       if (c < C) v.x = fmaf(xv[c], w[c].x, v.x), v.y = fmaf(xv[c], w[c].y, v.y), v.z = fmaf(xv[c], w[c].z, v.z), v.w = fmaf(xv[c], w[c].w, v.w);
-    if (pos) {
-      const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)l * D + j);
-      v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
-    }
-    const float4 t = *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j);
-    *reinterpret_cast<float4*>(h + (size_t)row * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
-    l += rl, b += qb;
+    if (pos) v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+    const float4 t = temb_stride ? *reinterpret_cast<const float4*>(temb + (size_t)bb * temb_stride + j) : t0;
+    *reinterpret_cast<float4*>(h + (size_t)rw * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
+  };
+  auto advance = [&]() {
+    row += rs, l += rl, b += qb;
     if (l >= (unsigned)L) l -= (unsigned)L, ++b;
+  };
+  // two rows per iteration: both rows' loads are in flight before the first store
+  while (row < M) {
+    float xa[8], xb[8];
+    const unsigned r0 = row, b0 = b, l0 = l;
+    load_x(r0, xa);
+    const float4 p0 = pos ? *reinterpret_cast<const float4*>(pos + (size_t)l0 * D + j) : float4{0.f, 0.f, 0.f, 0.f};
+    advance();
+    const bool two = row < M;
+    const unsigned r1 = row, b1 = b, l1 = l;
+    float4 p1{0.f, 0.f, 0.f, 0.f};
+    if (two) {
+      load_x(r1, xb);
+      if (pos) p1 = *reinterpret_cast<const float4*>(pos + (size_t)l1 * D + j);
+      advance();
+    }
+    emit(r0, b0, l0, xa, p0);
+    if (two) emit(r1, b1, l1, xb, p1);
   }
 }
 
@@ -306,8 +325,10 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
   const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-    uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+    // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a mul_hi / mul_lo pair: the generator is the
+    // ALU floor of the noise-drawing kernels (k_prior writes 4 B per element and nothing else)
+    const uint64_t p0 = (uint64_t)M0 * c.x, p1 = (uint64_t)M1 * c.z;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     U4 n = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
     c = n;
     k0 += W0;
@@ -518,11 +539,21 @@ __global__ __launch_bounds__(256) void k_unembed_mfma(const float* __restrict__ 
     for (int g = 0; g < NG; ++g)
       hv[g] = (16 * g + 4 * q < D) ? *reinterpret_cast<const float4*>(hr + 16 * g) : float4{0.f, 0.f, 0.f, 0.f};
   };
+  // (SDE, C % 4 == 0) the tile's x / injected z quad is fetched together with its h rows
+  const bool quad = SDE && (C & 3) == 0 && 4 * q < C;
+  auto load_xz = [&](int t, float4& xv, float4& zv) {
+    if (quad) {
+      const size_t i0 = (size_t)min(16 * t + r, M - 1) * C + 4 * q;
+      xv = *reinterpret_cast<const float4*>(x + i0);
+      if (z) zv = *reinterpret_cast<const float4*>(z + i0);
+    }
+  };
   float4 hv[NG], hn[NG];
-  if (wave < ntiles) load_tile(wave, hv);
+  float4 xv{}, zv{}, xnx{}, znx{};
+  if (wave < ntiles) load_tile(wave, hv), load_xz(wave, xv, zv);
   for (int t = wave; t < ntiles; t += nwaves) {
     const bool more = t + nwaves < ntiles;
-    if (more) load_tile(t + nwaves, hn);
+    if (more) load_tile(t + nwaves, hn), load_xz(t + nwaves, xnx, znx);
     f32x4 acc = bias;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -544,9 +575,8 @@ __global__ __launch_bounds__(256) void k_unembed_mfma(const float* __restrict__ 
         const float Gl = G[row % L];
         float zz[4];
         if ((C & 3) == 0) {
-          const float4 xi = *reinterpret_cast<const float4*>(x + i0);
+          const float4 xi = xv;
           if (z) {
-            const float4 zv = *reinterpret_cast<const float4*>(z + i0);
             zz[0] = zv.x, zz[1] = zv.y, zz[2] = zv.z, zz[3] = zv.w;
           } else {
             normal4((elem_offset + i0) >> 2, seed, step, zz);
@@ -562,6 +592,7 @@ __global__ __launch_bounds__(256) void k_unembed_mfma(const float* __restrict__ 
     if (more) {
 #pragma unroll
       for (int g = 0; g < NG; ++g) hv[g] = hn[g];
+      xv = xnx, zv = znx;
     }
   }
 }
@@ -682,33 +713,6 @@ hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* ou
   for (int k = 0; k < K; ++k) wv.w[k] = w_host[k];
   const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(k_weighted_sum, dim3(blocks), dim3(256), 0, s, hist, wv, out, K, n);
-  return hipGetLastError();
-}
-
-// compute_event_intensity's reduction (caching.py:546-556): mean over rows of || a_r - b_r ||_2.
-// One wave per row, per-block partial sums in a fixed order (deterministic); the host adds the <= 256 partials.
-__global__ __launch_bounds__(256) void k_row_delta_norm(const float* __restrict__ a, const float* __restrict__ b,
-                                                        float* __restrict__ partial, int rows, int D) {
-  __shared__ float wsum[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
-    float ss = 0.f;
-    for (int k = lane; k < D; k += 64) {
-      const float dlt = fabsf(a[(size_t)r * D + k] - b[(size_t)r * D + k]);
-      ss = fmaf(dlt, dlt, ss);
-    }
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-    acc += sqrtf(ss);
-  }
-  if (lane == 0) wsum[wave] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-
-hipError_t launch_row_delta_norm(const float* a, const float* b, float* partial, int nblocks, int rows, int D,
-                                 hipStream_t s) {
-  hipLaunchKernelGGL(k_row_delta_norm, dim3(nblocks), dim3(256), 0, s, a, b, partial, rows, D);
   return hipGetLastError();
 }
 

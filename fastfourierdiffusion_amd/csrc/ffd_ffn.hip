@@ -16,9 +16,18 @@
 // ways, each keeping the X fragments (MB*D/4 VGPRs) and a private Y^T accumulator
 // (MB*ceil(D/16)*4 VGPRs) resident and streaming only packed weights from L2
 // (2 coalesced float4 per lane per 16-wide F chunk).  Partial Y^T tiles are summed
-// in wave order through the LDS copy of the X tile (deterministic), which also
+// in a fixed order through the LDS copy of the X tile (deterministic), which also
 // provides the residual; LayerNorm2 runs on that tile and rows are written back
 // fully coalesced.
+//
+// Large M (MB >= 4) runs PERSISTENT: the grid is the number of workgroups the chip holds
+// (two per CU at MB = 4) and each workgroup walks tiles blockIdx.x, += gridDim.x.  The next
+// tile's X rows are fetched by LDS-DMA (global_load_lds_dwordx4: no VGPRs -- the kernel sits
+// at 252 of its 256 registers) into the second half of a double-buffered X image while the
+// current tile's main loop runs, and the weight prefetch of the last chunk wraps around to
+// chunk 0 of the next tile.  In-kernel stamps (ffd_probe_ffn_clock) had shown 57 us of a
+// workgroup's 157 us per tile outside the main loop (dispatch, X staging, first weight
+// fetch, epilogue) while the chip held 2.38 GHz: the matrix pipe, not the clock, was idle.
 #include "ffd_internal.h"
 
 namespace ffd {
@@ -34,7 +43,10 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
                                                   const float* __restrict__ W2r, const float* __restrict__ b2,
                                                   const float* __restrict__ gam, const float* __restrict__ bet,
-                                                  float* __restrict__ Y, int M, int F, int stagger) {
+                                                  float* __restrict__ Y, int M, int F, int stagger,
+                                                  unsigned long long* __restrict__ stamp) {
+  // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): shader-clock and 100 MHz real-time
+  // deltas around the main loops, written to memory nothing else reads (MI355X_MICROARCH.md, DVFS item 6)
   constexpr int S = lds_stride(D);
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
@@ -44,43 +56,56 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   constexpr int NGA = NG > 0 ? NG : 1;
   constexpr int R = 16 * MB;
   constexpr int S2 = ((D + 3) / 4) * 4 + 4;  // partial-sum row stride (16-byte aligned rows)
-  __shared__ __align__(16) float xs[R * S];
-  __shared__ __align__(16) float red[3 * R * S2];
+  constexpr bool DMA = MB >= 4;              // persistent over tiles, X image filled by LDS-DMA
+  // X image row stride: the LDS-DMA image is lane-linear (wave-uniform base + lane * 16 B), so its rows are whole
+  // float4 slots (S2, one pad slot per row; the fragment reads are then 2-way bank conflicted, once per tile); the
+  // register-staged small-M form keeps the conflict-free stride S.
+  constexpr int SX = DMA ? S2 : S;
+  constexpr int S4 = S2 / 4;
+  constexpr int NBUF = DMA ? 2 : 1;
+  constexpr int NRED = DMA ? 2 : 3;  // partial-sum buffers (the persistent form trades one for the second X image)
+  __shared__ __align__(16) float xsb[NBUF * R * SX];
+  __shared__ __align__(16) float red[NRED * R * S2];
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-  const int m0 = blockIdx.x * R;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = (M + R - 1) / R;
 
-  // ---- stage the X tile (coalesced float4) and pull this wave's B fragments ----
-  {
-    const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)m0 * D);
-    const int rows_valid = min(R, M - m0);
+  // a tile's X rows -> image `b`, asynchronously (rows past M repeat the last valid row; they are never stored)
+  auto issue_dma = [&](int t, int b) {
+    const int rows_valid = min(R, M - t * R);
+    const float* Xt = X + (size_t)t * R * D;
+    constexpr int NPC = (R * S4 + 63) / 64;
+    for (int pc = wave; pc < NPC; pc += 4) {
+      const int p = pc * 64 + lane;  // float4 slot of the image
+      const int r = p / S4, c4 = p - r * S4;
+      const int rr = min(r, rows_valid - 1), cc = min(c4, D / 4 - 1);  // pad slot: any valid address
+      if (p < R * S4)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Xt + (size_t)rr * D + 4 * cc),
+                                         (lds_ptr_t)(xsb + b * R * SX + pc * 256), 16, 0, 0);
+    }
+  };
+
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (DMA) {
+    issue_dma(tile, 0);
+  } else {
+    // ---- stage the X tile (coalesced float4) ----
+    const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)tile * R * D);
+    const int rows_valid = min(R, M - tile * R);
     for (int i4 = threadIdx.x; i4 < R * D / 4; i4 += 256) {
       const int r = (4 * i4) / D, k = 4 * i4 - r * D;
       float4 v = (r < rows_valid) ? X4[i4] : float4{0.f, 0.f, 0.f, 0.f};
-      float2* dst = reinterpret_cast<float2*>(&xs[r * S + k]);  // S even: 8-byte aligned
+      float2* dst = reinterpret_cast<float2*>(&xsb[r * SX + k]);  // S even: 8-byte aligned
       dst[0] = float2{v.x, v.y};
       dst[1] = float2{v.z, v.w};
     }
   }
-  __syncthreads();
-  float xf[MB][KS];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * S + 4 * s + (lane >> 4)];
 
-  f32x4 yacc[CT][MB];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 yrem[NGA][MB];
-#pragma unroll
-  for (int g = 0; g < NGA; ++g)
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- main loop over this wave's quarter of F, 16 hidden units per chunk ----
+  // ---- this wave's quarter of F, 16 hidden units per chunk ----
   const int nchunk = F / 64;  // chunks per wave
   const int fc0 = wave * nchunk;
   const float4* W1q = reinterpret_cast<const float4*>(W1p) + (size_t)fc0 * G * 64 + lane;
@@ -111,175 +136,219 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   load_w2(0);
   // De-phase the two waves that share a SIMD (they come from two workgroups that start together and
   // run the same instruction stream, so without this they also stall together): the wave in the odd
-  // hardware wave slot starts its main loop `stagger` x 64 cycles late.
+  // hardware wave slot starts its first main loop `stagger` x 64 cycles late.
   if (stagger > 0) {
     const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot in the SIMD
     if (hwid & 1)
       for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
   }
-  for (int ci = 0; ci < nchunk; ++ci) {
-    const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;  // clamped: the last prefetch is a harmless re-read
-    // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
-    f32x4 h[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 q = w1[s >> 2];
-      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) h[mb] = mfma16(a, xf[mb][s], h[mb]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_w1(nx);
-    __builtin_amdgcn_sched_barrier(0);
-    // relu as one v_med3_f32 (x, 0, +inf) per element
+  unsigned long long st_clk = 0, st_rt = 0, st_acc = 0, st_acc_rt = 0;
+
+  for (;;) {  // tiles of this workgroup (a single iteration unless DMA)
+    float* xs = xsb + buf * R * SX;
+    const int m0 = tile * R;
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's image has landed
+    __syncthreads();
+    // ---- this wave's B fragments; then the next tile's rows start streaming into the other image ----
+    float xf[MB][KS];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[mb][r] = __builtin_amdgcn_fmed3f(h[mb][r], 0.f, __builtin_inff());
-    // GEMM2: Y^T += W2[:, chunk] H^T chunk ; accumulator register r is the k-step
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        const float4 q = w2[ct];
-        const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
-      }
-    if (NG > 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int g = 0; g < NGA; ++g) {
-          const float4 q = w2r[g];
-          const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb)
-            yrem[g][mb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, h[mb][r], yrem[g][mb], 0, 0, 0);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    load_w2(nx);
-    __builtin_amdgcn_sched_barrier(0);
-  }
+      for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * SX + 4 * s + (lane >> 4)];
+    const int tile_next = tile + (int)gridDim.x;
+    if (DMA && tile_next < ntiles) issue_dma(tile_next, buf ^ 1);
 
-  // ---- deterministic cross-wave reduction: wave 0 adds its partial into the LDS X tile
-  // (= the residual), waves 1..3 park theirs in red[]; one barrier; every thread then sums
-  // x + p0 (already in xs) + p1 + p2 + p3 + b2 in that fixed order.
-  if (NG > 0) {
-    // add the four lane-quarter partials: afterwards every quarter holds the full sums
-    // yrem[g][mb][i] = Y^T[c0 + 4g + i][16 mb + (lane & 15)]
+    f32x4 yacc[CT][MB];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 yrem[NGA][MB];
 #pragma unroll
     for (int g = 0; g < NGA; ++g)
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = yrem[g][mb][i];
-          v += __shfl_xor(v, 16);
-          v += __shfl_xor(v, 32);
-          yrem[g][mb][i] = v;
-        }
-  }
-  if (wave == 0) {
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = 16 * ct + 4 * (lane >> 4) + r;
-          if (c < D) xs[(16 * mb + (lane & 15)) * S + c] += yacc[ct][mb][r];
-        }
-    if (NG > 0 && (lane >> 4) < NGA) {  // quarter q handles remainder group g = q
-      const int g = lane >> 4;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float v = 0.f;
-#pragma unroll
-          for (int gg = 0; gg < NGA; ++gg) v = (gg == g) ? yrem[gg][mb][i] : v;
-          xs[(16 * mb + (lane & 15)) * S + 16 * CT + 4 * g + i] += v;
-        }
-    }
-  } else {
-    float* rw = red + (size_t)(wave - 1) * R * S2;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const int c = 16 * ct + 4 * (lane >> 4);
-        if (c < D)
-          *reinterpret_cast<float4*>(&rw[(16 * mb + (lane & 15)) * S2 + c]) =
-              float4{yacc[ct][mb][0], yacc[ct][mb][1], yacc[ct][mb][2], yacc[ct][mb][3]};
-      }
-    if (NG > 0 && (lane >> 4) < NGA) {
-      const int g = lane >> 4;
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        float4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int gg = 0; gg < NGA; ++gg)
-          if (gg == g) v = float4{yrem[gg][mb][0], yrem[gg][mb][1], yrem[gg][mb][2], yrem[gg][mb][3]};
-        *reinterpret_cast<float4*>(&rw[(16 * mb + (lane & 15)) * S2 + 16 * CT + 4 * g]) = v;
-      }
-    }
-  }
-  __syncthreads();
+      for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- + b2, LayerNorm2, coalesced store ----
-  constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
-  const int row = threadIdx.x / TPR, sub = threadIdx.x % TPR;
-  const int m = m0 + row;
-  float vals[cdiv(D, TPR)];
-  float sum = 0.f;
+    if (stamp) st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();  // scalar: stays in SGPRs
+    for (int ci = 0; ci < nchunk; ++ci) {
+      const int nx = (ci + 1 < nchunk) ? ci + 1 : 0;  // the last prefetch wraps to chunk 0 = the next tile's first chunk
+      // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
+      f32x4 h[MB];
 #pragma unroll
-  for (int i = 0; i < cdiv(D, TPR); ++i) {
-    const int c = sub + i * TPR;
-    float v = 0.f;
-    if (c < D) {
-      v = xs[row * S + c];
-      v += red[(0 * R + row) * S2 + c];
-      v += red[(1 * R + row) * S2 + c];
-      v += red[(2 * R + row) * S2 + c];
-      v += b2[c];
-      sum += v;
+      for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4 q = w1[s >> 2];
+        const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) h[mb] = mfma16(a, xf[mb][s], h[mb]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w1(nx);
+      __builtin_amdgcn_sched_barrier(0);
+      // relu as one v_med3_f32 (x, 0, +inf) per element
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[mb][r] = __builtin_amdgcn_fmed3f(h[mb][r], 0.f, __builtin_inff());
+      // GEMM2: Y^T += W2[:, chunk] H^T chunk ; accumulator register r is the k-step
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const float4 q = w2[ct];
+          const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
+#pragma unroll
+          for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
+        }
+      if (NG > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int g = 0; g < NGA; ++g) {
+            const float4 q = w2r[g];
+            const float a = r == 0 ? q.x : r == 1 ? q.y : r == 2 ? q.z : q.w;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+              yrem[g][mb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, h[mb][r], yrem[g][mb], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      load_w2(nx);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    vals[i] = v;
-  }
-#pragma unroll
-  for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  const float mean = sum * (1.0f / D);
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < cdiv(D, TPR); ++i) {
-    const int c = sub + i * TPR;
-    if (c < D) {
-      float dlt = vals[i] - mean;
-      ss = fmaf(dlt, dlt, ss);
+    if (stamp) {
+      st_acc += __builtin_amdgcn_s_memtime() - st_clk;
+      st_acc_rt += __builtin_amdgcn_s_memrealtime() - st_rt;
     }
-  }
+
+    // ---- deterministic cross-wave reduction through LDS, fixed order of additions:
+    //   3 buffers (small M): wave 0 adds its partial into the X tile (= the residual), waves 1..3 park theirs;
+    //                        row sum = ((((x + p0) + p1) + p2) + p3) + b2
+    //   2 buffers (DMA):     wave 0 -> X tile, waves 1, 2 park; barrier; wave 3 adds into wave 1's buffer;
+    //                        row sum = (((x + p0) + (p1 + p3)) + p2) + b2
+    if (NG > 0) {
+      // add the four lane-quarter partials: afterwards every quarter holds the full sums
+      // yrem[g][mb][i] = Y^T[c0 + 4g + i][16 mb + (lane & 15)]
 #pragma unroll
-  for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
-  if (m < M) {
+      for (int g = 0; g < NGA; ++g)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = yrem[g][mb][i];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            yrem[g][mb][i] = v;
+          }
+    }
+    // acc = true: add to what the buffer holds (row stride st), else overwrite
+    auto put_partial = [&](float* dst, int st, bool acc) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = 16 * ct + 4 * (lane >> 4) + r;
+            if (c < D) {
+              float* q = &dst[(16 * mb + (lane & 15)) * st + c];
+              *q = acc ? *q + yacc[ct][mb][r] : yacc[ct][mb][r];
+            }
+          }
+      if (NG > 0 && (lane >> 4) < NGA) {  // quarter q handles remainder group g = q
+        const int g = lane >> 4;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float v = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < NGA; ++gg) v = (gg == g) ? yrem[gg][mb][i] : v;
+            float* q = &dst[(16 * mb + (lane & 15)) * st + 16 * CT + 4 * g + i];
+            *q = acc ? *q + v : v;
+          }
+      }
+    };
+    if (wave == 0) put_partial(xs, SX, true);
+    else if (wave <= NRED) put_partial(red + (size_t)(wave - 1) * R * S2, S2, false);
+    __syncthreads();
+    if (NRED == 2) {
+      if (wave == 3) put_partial(red, S2, true);
+      __syncthreads();
+    }
+
+    // ---- + b2, LayerNorm2, coalesced store ----
+    constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
+    const int row = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+    const int m = m0 + row;
+    float vals[cdiv(D, TPR)];
+    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < cdiv(D, TPR); ++i) {
       const int c = sub + i * TPR;
-      if (c < D) Y[(size_t)m * D + c] = (vals[i] - mean) * rstd * gam[c] + bet[c];
+      float v = 0.f;
+      if (c < D) {
+        v = xs[row * SX + c];
+#pragma unroll
+        for (int k = 0; k < NRED; ++k) v += red[(k * R + row) * S2 + c];
+        v += b2[c];
+        sum += v;
+      }
+      vals[i] = v;
     }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < cdiv(D, TPR); ++i) {
+      const int c = sub + i * TPR;
+      if (c < D) {
+        float dlt = vals[i] - mean;
+        ss = fmaf(dlt, dlt, ss);
+      }
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+    if (m < M) {
+#pragma unroll
+      for (int i = 0; i < cdiv(D, TPR); ++i) {
+        const int c = sub + i * TPR;
+        if (c < D) Y[(size_t)m * D + c] = (vals[i] - mean) * rstd * gam[c] + bet[c];
+      }
+    }
+    if (!DMA || tile_next >= ntiles) break;
+    tile = tile_next;
+    buf ^= 1;
+    // (the barrier at the top of the next iteration orders this tile's LDS reads before the next reduction's
+    //  writes: the images alternate, and `red` is next written after that barrier)
+  }
+  if (stamp && threadIdx.x == 0) {
+    stamp[2 * blockIdx.x] = st_acc;
+    stamp[2 * blockIdx.x + 1] = st_acc_rt;
   }
 }
 
+int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 int g_ffn_stagger = -1;     // x64 cycles of start delay for the odd wave slot of each SIMD; -1 = heuristic (ffd_tune "ffn_stagger")
 int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
 int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
 
 template <int D>
-static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s) {
+static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
+                               unsigned long long* stamp) {
   // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
   // and is the default once the grid fills the chip; smaller tiles for small batches.
   int mb = g_ffn_mb_override;
@@ -292,14 +361,20 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   // (measured 469 -> 457 us on the 95744 x 72 x 2048 shape, tools/sweep_stagger.py).
   const int stagger = g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0;
   dim3 block(256);
+  // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
+  const int resident = num_cus() * (mb == 4 ? 2 : 1) * (g_ffn_persist > 0 ? g_ffn_persist : 1);
+  auto grid_of = [&](int mbv) {
+    const int ntiles = cdiv(M, 16 * mbv);
+    return dim3((mbv >= 4 && g_ffn_persist != 0 && ntiles > resident) ? resident : ntiles);
+  };
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
     if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
-      hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,   \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger);                                             \
+      hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,             \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp);                                      \
     else                                                                                                          \
-      hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), dim3(cdiv(M, 16 * MBV)), block, 0, s, X, w.w1p, w.b1, w.w2p,  \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger);                                             \
+      hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,            \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp);                                      \
   } while (0)
   switch (mb) {
     case 8: FFD_LAUNCH_FFN(8); break;
@@ -311,12 +386,19 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   return hipGetLastError();
 }
 
-hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s) {
+int ffn_tile_rows(int M) {  // rows per workgroup launch_ffn_ln picks (one stamp pair per workgroup)
+  int mb = g_ffn_mb_override;
+  if (mb != 1 && mb != 2 && mb != 4 && mb != 8) mb = cdiv(M, 64) >= 512 ? 4 : cdiv(M, 32) >= 512 ? 2 : 1;
+  return 16 * mb;
+}
+
+hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
+                         unsigned long long* stamp) {
   if (M <= 0) return hipSuccess;
   if (F % 64 != 0) return hipErrorInvalidValue;
   switch (D) {
 #define X(d) \
-    case d: return launch_ffn_d<d>(X, w, Y, M, F, s);
+    case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp);
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;

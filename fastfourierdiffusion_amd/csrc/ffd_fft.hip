@@ -354,9 +354,12 @@ __device__ __forceinline__ float2* pow2_fft(float2* x, float2* y, const float2* 
 }
 
 // Z (N x CG complex) -> packed ortho spectrum rows (L x CG floats) in `st`, scaled by sc.
+// Work items per channel: item 0 = the two self-paired bins k = 0 and k = N/2, item k (0 < k < N/2) = the pair (k, N-k):
+// max(1, N/2) items, a whole number of passes over the workgroup for the power-of-two shapes.
 __device__ __forceinline__ void pow2_split_fwd(const float2* __restrict__ Z, float* __restrict__ st,
                                                const float2* __restrict__ T, int N, int CG, int cg, int lc, float sc) {
-  const int nk = ((N >> 1) + 1) << lc;
+  const int h = N >> 1;
+  const int nk = (h > 0 ? h : 1) << lc;
   for (int t = threadIdx.x; t < nk; t += blockDim.x) {
     const int c = t & ((1 << lc) - 1);
     if (c >= cg) continue;
@@ -365,6 +368,11 @@ __device__ __forceinline__ void pow2_split_fwd(const float2* __restrict__ Z, flo
       const float2 a = Z[c];
       st[c] = (a.x + a.y) * sc;
       st[N * CG + c] = (a.x - a.y) * sc;
+      if (h > 0) {  // X[N/2] = conj(Z[N/2])
+        const float2 m = Z[h * CG + c];
+        st[h * CG + c] = m.x * sc;
+        st[(N + h) * CG + c] = -m.y * sc;
+      }
     } else {
       const float2 A = Z[k * CG + c], B = Z[(N - k) * CG + c];
       const float2 E = make_float2(0.5f * (A.x + B.x), 0.5f * (A.y - B.y));
@@ -372,10 +380,8 @@ __device__ __forceinline__ void pow2_split_fwd(const float2* __restrict__ Z, flo
       const float2 P = cmul(T[k], D);
       st[k * CG + c] = (E.x + P.x) * sc;
       st[(N + k) * CG + c] = (E.y + P.y) * sc;
-      if (k != N - k) {
-        st[(N - k) * CG + c] = (E.x - P.x) * sc;
-        st[(2 * N - k) * CG + c] = -(E.y - P.y) * sc;
-      }
+      st[(N - k) * CG + c] = (E.x - P.x) * sc;
+      st[(2 * N - k) * CG + c] = -(E.y - P.y) * sc;
     }
   }
   __syncthreads();
@@ -384,7 +390,8 @@ __device__ __forceinline__ void pow2_split_fwd(const float2* __restrict__ Z, flo
 // packed spectrum rows (L x CG floats) in `st` -> Z (N x CG complex), unnormalised
 __device__ __forceinline__ void pow2_split_inv(const float* __restrict__ st, float2* __restrict__ Z,
                                                const float2* __restrict__ T, int N, int CG, int cg, int lc) {
-  const int nk = ((N >> 1) + 1) << lc;
+  const int h = N >> 1;
+  const int nk = (h > 0 ? h : 1) << lc;
   for (int t = threadIdx.x; t < nk; t += blockDim.x) {
     const int c = t & ((1 << lc) - 1);
     if (c >= cg) continue;
@@ -392,34 +399,61 @@ __device__ __forceinline__ void pow2_split_inv(const float* __restrict__ st, flo
     if (k == 0) {
       const float r0 = st[c], rn = st[N * CG + c];
       Z[c] = make_float2(r0 + rn, r0 - rn);
+      if (h > 0) Z[h * CG + c] = make_float2(2.f * st[h * CG + c], -2.f * st[(N + h) * CG + c]);  // 2 conj(X[N/2])
     } else {
       const float2 X = make_float2(st[k * CG + c], st[(N + k) * CG + c]);
-      const float2 Y = (k != N - k) ? make_float2(st[(N - k) * CG + c], st[(2 * N - k) * CG + c]) : X;  // X[N-k]
+      const float2 Y = make_float2(st[(N - k) * CG + c], st[(2 * N - k) * CG + c]);  // X[N-k]
       const float2 S = make_float2(X.x + Y.x, X.y - Y.y);    // X[k] + conj X[N-k]
       const float2 Dd = make_float2(X.x - Y.x, X.y + Y.y);   // X[k] - conj X[N-k]
       float2 w = T[k];
       w.y = -w.y;
       const float2 Q = cmul(w, Dd);
-      Z[k * CG + c] = make_float2(S.x - Q.y, S.y + Q.x);                       // S + iQ
-      if (k != N - k) Z[(N - k) * CG + c] = make_float2(S.x + Q.y, -(S.y - Q.x));  // conj(S - iQ)
+      Z[k * CG + c] = make_float2(S.x - Q.y, S.y + Q.x);           // S + iQ
+      Z[(N - k) * CG + c] = make_float2(S.x + Q.y, -(S.y - Q.x));  // conj(S - iQ)
     }
   }
   __syncthreads();
 }
 
-// slab (L x C) of one sample -> z image (even rows real parts, odd rows imaginary parts)
+// Slab I/O of the VEC path (CG == C, C % 4 == 0: the (L x C) slab is a flat array of n4 = L C / 4 float4).  The
+// kernels are persistent over samples and keep the NEXT sample's slab in registers (PF float4 per thread) while the
+// current one is transformed in LDS, so a workgroup always has a slab of HBM loads in flight.
+constexpr int PF = 8;  // float4 prefetch registers per thread: slabs up to 8 * 256 float4 = 32 KiB are prefetched
+
+__device__ __forceinline__ void slab_prefetch(const float* __restrict__ src, int n4, float4 (&pre)[PF]) {
+  const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int f = threadIdx.x + i * 256;
+    if (f < n4) pre[i] = s4[f];
+  }
+}
+
+// time-domain slab -> z image (even rows real parts, odd rows imaginary parts): z[n][c] = (x[2n][c], x[2n+1][c])
+// row of float4 slot f in a slab with C4 float4 per row (C4 a power of two in every shipped shape: no division)
+__device__ __forceinline__ int slab_row(int f, int C4) { return (C4 & (C4 - 1)) == 0 ? f >> (31 - __builtin_clz(C4)) : f / C4; }
+
+__device__ __forceinline__ void z_put(float* __restrict__ zf, int f, float4 v, int C4, int CG) {
+  const int l = slab_row(f, C4), cq = (f - l * C4) << 2;
+  float* d = zf + (((l >> 1) * CG + cq) << 1) + (l & 1);
+  d[0] = v.x, d[2] = v.y, d[4] = v.z, d[6] = v.w;
+}
+
 template <bool VEC>
 __device__ __forceinline__ void pow2_load_time(const float* __restrict__ src, float2* __restrict__ z, int L, int C,
-                                               int c0, int CG, int cg) {
+                                               int c0, int CG, int cg, bool prefetched, const float4 (&pre)[PF]) {
   float* zf = reinterpret_cast<float*>(z);
   if (VEC) {
     const int C4 = C >> 2, n4 = L * C4;
-    const float4* s4 = reinterpret_cast<const float4*>(src);
-    for (int f = threadIdx.x; f < n4; f += blockDim.x) {
-      const float4 v = s4[f];
-      const int l = f / C4, cq = (f - l * C4) << 2;
-      float* d = zf + (((l >> 1) * CG + cq) << 1) + (l & 1);
-      d[0] = v.x, d[2] = v.y, d[4] = v.z, d[6] = v.w;
+    if (prefetched) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int f = threadIdx.x + i * 256;
+        if (f < n4) z_put(zf, f, pre[i], C4, CG);
+      }
+    } else {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      for (int f = threadIdx.x; f < n4; f += blockDim.x) z_put(zf, f, s4[f], C4, CG);
     }
   } else {
     for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
@@ -439,7 +473,7 @@ __device__ __forceinline__ void pow2_store_time(const float2* __restrict__ z, fl
     const int C4 = C >> 2, n4 = L * C4;
     float4* d4 = reinterpret_cast<float4*>(dst);
     for (int f = threadIdx.x; f < n4; f += blockDim.x) {
-      const int l = f / C4, cq = (f - l * C4) << 2;
+      const int l = slab_row(f, C4), cq = (f - l * C4) << 2;
       const float* p = zf + (((l >> 1) * CG + cq) << 1) + (l & 1);
       d4[f] = make_float4(p[0] * sc, p[2] * sc, p[4] * sc, p[6] * sc);
     }
@@ -451,139 +485,182 @@ __device__ __forceinline__ void pow2_store_time(const float2* __restrict__ z, fl
   }
 }
 
-// dft (INVERSE = false) / idft (true) of one sample slab per workgroup, with the optional affine wrappers:
+// dft (INVERSE = false) / idft (true), persistent over the samples b = blockIdx.x, += gridDim.x, with the optional
+// affine wrappers:
 //   forward : out = (dft(x) - a0) / a1                    (datamodules.py:42-43,61-62; a0 = mean, a1 = std, (L, C))
 //   inverse : out = idft(x * a0 + a1)                     (cmd/sample.py:107-113;     a0 = std,  a1 = mean)
 // each product / sum rounded separately like the reference's tensor ops.
 template <bool INVERSE, bool VEC>
 __global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float2* __restrict__ Wg, Pow2Plan plan, int L, int C, int CG,
-                                                   int lc, float scale, const float* __restrict__ a0,
+                                                   const float2* __restrict__ Wg, Pow2Plan plan, int B, int L, int C,
+                                                   int CG, int lc, float scale, const float* __restrict__ a0,
                                                    const float* __restrict__ a1) {
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;                 // L twiddles
   float2* bufA = sm + L;          // N * CG complex
   float2* bufB = bufA + N * CG;   // N * CG complex == L * CG floats
-  const int b = blockIdx.x;
   const int c0 = blockIdx.y * CG;
   const int cg = min(CG, C - c0);
-  const float* src = in + (size_t)b * L * C;
-  float* dst = out + (size_t)b * L * C;
+  const int n4 = (L * C) >> 2;
+  const bool pf = VEC && n4 <= PF * 256;
   for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
-  if (!INVERSE) {
-    pow2_load_time<VEC>(src, bufA, L, C, c0, CG, cg);  // (barrier inside; also covers the twiddle table)
-    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
-    float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
-    pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
-    if (VEC) {
-      const int n4 = (L * C) >> 2;
-      const float4* s4 = reinterpret_cast<const float4*>(st);
-      float4* d4 = reinterpret_cast<float4*>(dst);
-      for (int f = threadIdx.x; f < n4; f += blockDim.x) {
-        float4 v = s4[f];
-        if (a0) {
-          const float4 mu = reinterpret_cast<const float4*>(a0)[f], sd = reinterpret_cast<const float4*>(a1)[f];
-          v = make_float4(__fdiv_rn(__fsub_rn(v.x, mu.x), sd.x), __fdiv_rn(__fsub_rn(v.y, mu.y), sd.y),
-                          __fdiv_rn(__fsub_rn(v.z, mu.z), sd.z), __fdiv_rn(__fsub_rn(v.w, mu.w), sd.w));
+  float4 pre[PF];
+  if (pf && (int)blockIdx.x < B) slab_prefetch(in + (size_t)blockIdx.x * L * C, n4, pre);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* src = in + (size_t)b * L * C;
+    float* dst = out + (size_t)b * L * C;
+    const int bn = b + gridDim.x;
+    if (!INVERSE) {
+      pow2_load_time<VEC>(src, bufA, L, C, c0, CG, cg, pf, pre);  // (barrier inside; also covers the twiddle table)
+      if (pf && bn < B) slab_prefetch(in + (size_t)bn * L * C, n4, pre);
+      float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+      float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
+      pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+      if (VEC) {
+        const float4* s4 = reinterpret_cast<const float4*>(st);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+          float4 v = s4[f];
+          if (a0) {
+            const float4 mu = reinterpret_cast<const float4*>(a0)[f], sd = reinterpret_cast<const float4*>(a1)[f];
+            v = make_float4(__fdiv_rn(__fsub_rn(v.x, mu.x), sd.x), __fdiv_rn(__fsub_rn(v.y, mu.y), sd.y),
+                            __fdiv_rn(__fsub_rn(v.z, mu.z), sd.z), __fdiv_rn(__fsub_rn(v.w, mu.w), sd.w));
+          }
+          d4[f] = v;
         }
-        d4[f] = v;
+      } else {
+        for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+          const int o = idx / cg, cc = idx - o * cg;
+          float v = st[o * CG + cc];
+          const size_t gi = (size_t)o * C + c0 + cc;
+          if (a0) v = __fdiv_rn(__fsub_rn(v, a0[gi]), a1[gi]);
+          dst[gi] = v;
+        }
       }
     } else {
-      for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
-        const int o = idx / cg, cc = idx - o * cg;
-        float v = st[o * CG + cc];
-        const size_t gi = (size_t)o * C + c0 + cc;
-        if (a0) v = __fdiv_rn(__fsub_rn(v, a0[gi]), a1[gi]);
-        dst[gi] = v;
-      }
-    }
-  } else {
-    float* st = reinterpret_cast<float*>(bufB);
-    if (VEC) {
-      const int n4 = (L * C) >> 2;
-      const float4* s4 = reinterpret_cast<const float4*>(src);
-      for (int f = threadIdx.x; f < n4; f += blockDim.x) {
-        float4 v = s4[f];
-        if (a0) {
-          const float4 sd = reinterpret_cast<const float4*>(a0)[f], mu = reinterpret_cast<const float4*>(a1)[f];
-          v = make_float4(__fadd_rn(__fmul_rn(v.x, sd.x), mu.x), __fadd_rn(__fmul_rn(v.y, sd.y), mu.y),
-                          __fadd_rn(__fmul_rn(v.z, sd.z), mu.z), __fadd_rn(__fmul_rn(v.w, sd.w), mu.w));
+      float* st = reinterpret_cast<float*>(bufB);
+      if (VEC) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        auto put = [&](int f, float4 v) {
+          if (a0) {
+            const float4 sd = reinterpret_cast<const float4*>(a0)[f], mu = reinterpret_cast<const float4*>(a1)[f];
+            v = make_float4(__fadd_rn(__fmul_rn(v.x, sd.x), mu.x), __fadd_rn(__fmul_rn(v.y, sd.y), mu.y),
+                            __fadd_rn(__fmul_rn(v.z, sd.z), mu.z), __fadd_rn(__fmul_rn(v.w, sd.w), mu.w));
+          }
+          reinterpret_cast<float4*>(st)[f] = v;
+        };
+        if (pf) {
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            const int f = threadIdx.x + i * 256;
+            if (f < n4) put(f, pre[i]);
+          }
+        } else {
+          for (int f = threadIdx.x; f < n4; f += blockDim.x) put(f, s4[f]);
         }
-        reinterpret_cast<float4*>(st)[f] = v;
+      } else {
+        for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+          const int o = idx / cg, cc = idx - o * cg;
+          const size_t gi = (size_t)o * C + c0 + cc;
+          float v = src[gi];
+          if (a0) v = __fadd_rn(__fmul_rn(v, a0[gi]), a1[gi]);
+          st[o * CG + cc] = v;
+        }
       }
-    } else {
-      for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
-        const int o = idx / cg, cc = idx - o * cg;
-        const size_t gi = (size_t)o * C + c0 + cc;
-        float v = src[gi];
-        if (a0) v = __fadd_rn(__fmul_rn(v, a0[gi]), a1[gi]);
-        st[o * CG + cc] = v;
-      }
+      __syncthreads();
+      if (pf && bn < B) slab_prefetch(in + (size_t)bn * L * C, n4, pre);
+      pow2_split_inv(st, bufA, T, N, CG, cg, lc);
+      float2* z = pow2_fft<true>(bufA, bufB, T, plan, N, CG, cg, lc);
+      pow2_store_time<VEC>(z, dst, L, C, c0, CG, cg, scale);
     }
-    __syncthreads();
-    pow2_split_inv(st, bufA, T, N, CG, cg, lc);
-    float2* z = pow2_fft<true>(bufA, bufB, T, plan, N, CG, cg, lc);
-    pow2_store_time<VEC>(z, dst, L, C, c0, CG, cg, scale);
+    __syncthreads();  // the LDS images are rewritten by the next sample
   }
 }
 
 // FreSca on the power-of-two path: per-sample |X_k| partial sums, and FFT -> per-bin scale -> inverse FFT.
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_fresca_spectrum_pow2(const float* __restrict__ in, float* __restrict__ partial,
-                                                              const float2* __restrict__ Wg, Pow2Plan plan, int L, int C,
-                                                              int CG, int lc, float scale) {
+                                                              const float2* __restrict__ Wg, Pow2Plan plan, int B, int L,
+                                                              int C, int CG, int lc, float scale) {
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;
   float2* bufA = sm + L;
   float2* bufB = bufA + N * CG;
-  const int b = blockIdx.x, c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  const int c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  const int n4 = (L * C) >> 2;
+  const bool pf = VEC && n4 <= PF * 256;
   for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
-  pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg);
-  float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
-  float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
-  pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
-  const int nf = N + 1;
-  for (int k = threadIdx.x; k < nf; k += blockDim.x) {
-    const bool has_im = k >= 1 && k < N;
-    float acc = 0.f;
-    for (int c = 0; c < cg; ++c) {
-      const float re = st[k * CG + c], im = has_im ? st[(N + k) * CG + c] : 0.f;
-      acc += sqrtf(fmaf(re, re, im * im));
+  float4 pre[PF];
+  if (pf && (int)blockIdx.x < B) slab_prefetch(in + (size_t)blockIdx.x * L * C, n4, pre);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg, pf, pre);
+    if (pf && b + (int)gridDim.x < B) slab_prefetch(in + (size_t)(b + gridDim.x) * L * C, n4, pre);
+    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+    float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
+    pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+    const int nf = N + 1;
+    for (int k = threadIdx.x; k < nf; k += blockDim.x) {
+      const bool has_im = k >= 1 && k < N;
+      float acc = 0.f;
+      for (int c = 0; c < cg; ++c) {
+        const float re = st[k * CG + c], im = has_im ? st[(N + k) * CG + c] : 0.f;
+        acc += sqrtf(fmaf(re, re, im * im));
+      }
+      partial[((size_t)b * gridDim.y + blockIdx.y) * nf + k] = acc;
     }
-    partial[((size_t)b * gridDim.y + blockIdx.y) * nf + k] = acc;
+    __syncthreads();
   }
 }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restrict__ in, float* __restrict__ out,
-                                                           const float2* __restrict__ Wg, Pow2Plan plan, int L, int C,
-                                                           int CG, int lc, const int* __restrict__ rc_dev, float rc_host,
-                                                           float low, float high, float scale) {
+                                                           const float2* __restrict__ Wg, Pow2Plan plan, int B, int L,
+                                                           int C, int CG, int lc, const int* __restrict__ rc_dev,
+                                                           float rc_host, float low, float high, float scale) {
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;
   float2* bufA = sm + L;
   float2* bufB = bufA + N * CG;
-  const int b = blockIdx.x, c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  const int c0 = blockIdx.y * CG, cg = min(CG, C - c0);
+  const int n4 = (L * C) >> 2;
+  const bool pf = VEC && n4 <= PF * 256;
   for (int i = threadIdx.x; i < L; i += blockDim.x) T[i] = Wg[i];
-  pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg);
-  float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
-  float2* other = (Z == bufA) ? bufB : bufA;
-  float* st = reinterpret_cast<float*>(other);
-  pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
   // low-pass set: k <= Rc (energy: integer index from the cutoff kernel; spatial: Rc = r0 * n_freq)
   const float rc = rc_dev ? (float)(*rc_dev) : rc_host;
-  for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
-    const int r = idx / cg, cc = idx - r * cg;
-    const int k = r <= N ? r : r - N;  // rows N+1.. hold Im X_k, k = r - N
-    st[r * CG + cc] *= ((float)k <= rc) ? low : high;
+  float4 pre[PF];
+  if (pf && (int)blockIdx.x < B) slab_prefetch(in + (size_t)blockIdx.x * L * C, n4, pre);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg, pf, pre);
+    if (pf && b + (int)gridDim.x < B) slab_prefetch(in + (size_t)(b + gridDim.x) * L * C, n4, pre);
+    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+    float2* other = (Z == bufA) ? bufB : bufA;
+    float* st = reinterpret_cast<float*>(other);
+    pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
+    if (VEC) {  // rows are whole float4 groups of one bin
+      const int C4 = C >> 2;
+      for (int f = threadIdx.x; f < n4; f += blockDim.x) {
+        const int r = slab_row(f, C4);
+        const int k = r <= N ? r : r - N;  // rows N+1.. hold Im X_k, k = r - N
+        const float fac = ((float)k <= rc) ? low : high;
+        float4 v = reinterpret_cast<float4*>(st)[f];
+        reinterpret_cast<float4*>(st)[f] = make_float4(v.x * fac, v.y * fac, v.z * fac, v.w * fac);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < L * cg; idx += blockDim.x) {
+        const int r = idx / cg, cc = idx - r * cg;
+        const int k = r <= N ? r : r - N;
+        st[r * CG + cc] *= ((float)k <= rc) ? low : high;
+      }
+    }
+    __syncthreads();
+    pow2_split_inv(st, Z, T, N, CG, cg, lc);
+    float2* z = pow2_fft<true>(Z, other, T, plan, N, CG, cg, lc);
+    pow2_store_time<VEC>(z, out + (size_t)b * L * C, L, C, c0, CG, cg, scale);
+    __syncthreads();
   }
-  __syncthreads();
-  pow2_split_inv(st, Z, T, N, CG, cg, lc);
-  float2* z = pow2_fft<true>(Z, other, T, plan, N, CG, cg, lc);
-  pow2_store_time<VEC>(z, out + (size_t)b * L * C, L, C, c0, CG, cg, scale);
 }
 
 static bool is_pow2(int L) { return L >= 2 && (L & (L - 1)) == 0; }
@@ -614,6 +691,13 @@ static int ceil_log2(int v) {
   int l = 0;
   while ((1 << l) < v) ++l;
   return l;
+}
+// persistent grid: as many workgroups as the LDS image lets a CU hold (at most 8), times the CU count
+static int persistent_blocks(int B, size_t lds) {
+  int per_cu = (int)((160 * 1024) / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  const int cap = 256 * per_cu;
+  return B < cap ? B : cap;
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -689,11 +773,11 @@ hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inve
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const int lc = ceil_log2(CG);
     const bool vec = CG == C && C % 4 == 0 && aligned16(in) && aligned16(out) && aligned16(a0) && aligned16(a1);
-    dim3 grid(B, cdiv(C, CG)), block(256);
+    dim3 grid(persistent_blocks(B, lds), cdiv(C, CG)), block(256);
 #define FFD_RFFT(INV, VEC)                                                                                   \
   do {                                                                                                       \
     if ((e = allow_lds(k_rfft_pow2<INV, VEC>, lds)) != hipSuccess) return e;                                 \
-    hipLaunchKernelGGL((k_rfft_pow2<INV, VEC>), grid, block, lds, s, in, out, W, plan, L, C, CG, lc, scale, a0, a1); \
+    hipLaunchKernelGGL((k_rfft_pow2<INV, VEC>), grid, block, lds, s, in, out, W, plan, B, L, C, CG, lc, scale, a0, a1); \
   } while (0)
     if (inverse) {
       if (vec) FFD_RFFT(true, true); else FFD_RFFT(true, false);
@@ -753,13 +837,14 @@ static hipError_t launch_fresca_apply(const float* in, float* out, const float2*
   hipError_t e;
   if (g.pow2) {
     const bool vec = g.CG == C && C % 4 == 0 && aligned16(in) && aligned16(out);
+    grid.x = persistent_blocks(B, g.lds);
     if (vec) {
       if ((e = allow_lds(k_fresca_apply_pow2<true>, g.lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_fresca_apply_pow2<true>, grid, block, g.lds, s, in, out, W, g.plan2, L, C, g.CG, g.lc, rc_dev,
+      hipLaunchKernelGGL(k_fresca_apply_pow2<true>, grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc, rc_dev,
                          rc_host, low, high, sc);
     } else {
       if ((e = allow_lds(k_fresca_apply_pow2<false>, g.lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_fresca_apply_pow2<false>, grid, block, g.lds, s, in, out, W, g.plan2, L, C, g.CG, g.lc, rc_dev,
+      hipLaunchKernelGGL(k_fresca_apply_pow2<false>, grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc, rc_dev,
                          rc_host, low, high, sc);
     }
   } else {
@@ -789,12 +874,13 @@ hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L,
     int* rc = reinterpret_cast<int*>(work + (size_t)B * NGc * nf);
     dim3 grid(B, NGc), block(256);
     if (g.pow2) {
+      grid.x = persistent_blocks(B, g.lds);
       if (g.CG == C && C % 4 == 0 && aligned16(in)) {
         if ((e = allow_lds(k_fresca_spectrum_pow2<true>, g.lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fresca_spectrum_pow2<true>, grid, block, g.lds, s, in, partial, W, g.plan2, L, C, g.CG, g.lc, sc);
+        hipLaunchKernelGGL(k_fresca_spectrum_pow2<true>, grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG, g.lc, sc);
       } else {
         if ((e = allow_lds(k_fresca_spectrum_pow2<false>, g.lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fresca_spectrum_pow2<false>, grid, block, g.lds, s, in, partial, W, g.plan2, L, C, g.CG, g.lc, sc);
+        hipLaunchKernelGGL(k_fresca_spectrum_pow2<false>, grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG, g.lc, sc);
       }
     } else {
       if ((e = allow_lds(k_fresca_spectrum, g.lds)) != hipSuccess) return e;

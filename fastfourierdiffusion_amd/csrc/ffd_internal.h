@@ -55,15 +55,6 @@ struct LayerWeights {
   const float *w2r;     // w2rem (remainder rows d % 16 of linear2.weight, 4x4x1 MFMA A-operand order)
 };
 
-// The next layer's input projection, fused as the epilogue of k_layer (nreg = 0: none,
-// 1: Q only (pure-cache step), 3: Q,K,V); outputs are head-major (B,H,L,hd).
-struct NextProj {
-  const float* wp;
-  const float* bias;
-  float *q, *k, *v;
-  int nreg, L, H, hd;
-};
-
 hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s);
 hipError_t launch_pack_w2(const float* W2, float* W2p, int D, int F, hipStream_t s);
 // "w2rem": rows c >= 16*(D/16) of linear2.weight (D x F), in groups of 4, as the A operand of
@@ -112,15 +103,14 @@ hipError_t launch_linear(const float* X, const float* Wp, const float* bias, flo
 hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bias, const float* R, const float* g,
                                 const float* beta, float* Y, int M, int D, hipStream_t s);
 // Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
-hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s);
-// out-proj + LN1 + FFN + LN2 (+ next layer's projection) for 64-row tiles in one launch
-hipError_t launch_layer(const float* attn, const float* xres, const LayerWeights& w, float* Y, const NextProj& nx,
-                        int M, int D, int F, hipStream_t s);
+// stamp != nullptr (diagnostics): per-workgroup (shader-clock, 100 MHz real-time) deltas around the main loop
+hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
+                         unsigned long long* stamp = nullptr);
+int ffn_tile_rows(int M);
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
 extern int g_ffn_stagger;
-extern int g_fuse_layer;
-extern int g_attn_impl;
+extern int g_ffn_persist;
 extern int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
 size_t attn_pack_floats(int D, int H, int hpw, int q_only);
@@ -150,7 +140,7 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
 // large batches: input gates + recurrence of one residual LSTM layer in one launch (no gx tensor); in place on x
 bool lstm_mfma_selected(int B, int D);
-extern int g_lstm_mfma_min_batch;
+extern int g_lstm_mfma_min_batch, g_lstm_mfma_s;
 hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
                             hipStream_t s);
 
@@ -162,8 +152,6 @@ hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inve
 hipError_t launch_freq_decompose(const float* in, float* low, float* high, int B, int L, int D, double low_freq_ratio,
                                  hipStream_t s);
 hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, int C, hipStream_t s);
-hipError_t launch_row_delta_norm(const float* a, const float* b, float* partial, int nblocks, int rows, int D,
-                                 hipStream_t s);
 hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* out, int K, size_t n, hipStream_t s);
 // FreSca spectral scaling of a (B,L,C) score; work: B*(L/2+1) + 1 floats; strategy 0 spatial, 1 energy
 hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,

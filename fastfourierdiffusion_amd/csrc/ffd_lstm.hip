@@ -199,39 +199,66 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
 // (prefetched one step ahead; the four waves share the rows through L1) and double as the residual input.
 // 18 tiles over 4 waves split 5 / 5 / 4 / 4: the matrix pipe of the 5-tile SIMDs paces the step.
 // ---------------------------------------------------------------------------
-template <int D, int S>
-__global__ __launch_bounds__(256, 1) void k_lstm_mfma(float* __restrict__ x, const float* __restrict__ wih,
+template <int D, int S, int GRP>
+__global__ __launch_bounds__(256 * GRP, GRP) void k_lstm_mfma(float* __restrict__ x, const float* __restrict__ wih,
                                                       const float* __restrict__ whh, const float* __restrict__ bsum,
                                                       int B, int L) {
   constexpr int NT = D / 4;          // unit tiles of 4 units x 4 gates == k-steps of 4
   constexpr int NTW = (NT + 3) / 4;  // tiles per wave (upper bound)
+  constexpr int NG = (NT + 3) / 4;   // groups of 4 k-steps (one float4 of A fragments each)
   constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
-  __shared__ float hbuf[2][S][16][HS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // W_hh fragments stay in VGPRs (they sit on the serial h chain); the W_ih fragments and the biases are streamed from
+  // a wave-private LDS image, one ds_read_b128 per 4 k-steps -- with both matrices in registers (2 x 90 at d = 72)
+  // hipcc has no room left to keep the x / h fragments of a step in flight and serialises every load with its use.
+  extern __shared__ __align__(16) float lds[];
+  float4* wlds = reinterpret_cast<float4*>(lds);            // [wave 4][g NG][tt NTW][lane 64]
+  float4* blds = wlds + 4 * NG * NTW * 64;                  // [wave 4][tt NTW][lane 64]  (accumulator layout)
+  const int lane = threadIdx.x & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile ownership tests are s_cbranch, not exec masks
+  // GRP = 2: waves w and w + 4 own the SAME unit tiles for two different groups of 16 S samples.  They share a SIMD
+  // (a workgroup's waves are dealt to the SIMDs cyclically), so one's cell update / LDS waits run under the other's
+  // MFMAs, and they share the W_ih / bias image in LDS.
+  const int wave = wave8 & 3, grp = wave8 >> 2;
+  float* hbuf = reinterpret_cast<float*>(blds + 4 * NTW * 64) + grp * (2 * S * 16 * HS);  // per group: [2][S][16][HS]
   const int j = lane & 15, q = lane >> 4;
   const int t0 = wave * (NT / 4) + min(wave, NT % 4);
-  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);  // wave-uniform
+  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
+  // A wave with fewer than NTW tiles runs the MFMAs of its phantom tile on zero weights: the step is paced by the
+  // NTW-tile waves anyway (barrier), and the main loop stays straight-line code.
 
   // weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]) and biases (accumulator layout)
-  float wi[NTW][NT], wh[NTW][NT];
-  f32x4 bias[NTW];
+  float wh[NTW][NT];
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) {
     const int T = min(t0 + tt, NT - 1);
     const bool on = tt < ntw;
     const size_t row = (size_t)((j & 3) * D + 4 * T + (j >> 2)) * D;
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-      wi[tt][s] = on ? wih[row + 4 * s + q] : 0.f;
-      wh[tt][s] = on ? whh[row + 4 * s + q] : 0.f;
-    }
+    for (int s = 0; s < NT; ++s) wh[tt][s] = on ? whh[row + 4 * s + q] : 0.f;
+    if (grp == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
+      for (int g = 0; g < NG; ++g) {
+        float4 v;
+        v.x = (on && 4 * g + 0 < NT) ? wih[row + 4 * (4 * g + 0) + q] : 0.f;
+        v.y = (on && 4 * g + 1 < NT) ? wih[row + 4 * (4 * g + 1) + q] : 0.f;
+        v.z = (on && 4 * g + 2 < NT) ? wih[row + 4 * (4 * g + 2) + q] : 0.f;
+        v.w = (on && 4 * g + 3 < NT) ? wih[row + 4 * (4 * g + 3) + q] : 0.f;
+        wlds[((wave * NG + g) * NTW + tt) * 64 + lane] = v;
+      }
+      float4 bv;
+      bv.x = on ? bsum[0 * D + 4 * T + q] : 0.f;
+      bv.y = on ? bsum[1 * D + 4 * T + q] : 0.f;
+      bv.z = on ? bsum[2 * D + 4 * T + q] : 0.f;
+      bv.w = on ? bsum[3 * D + 4 * T + q] : 0.f;
+      blds[(wave * NTW + tt) * 64 + lane] = bv;
+    }
   }
-  for (int i = threadIdx.x; i < 2 * S * 16 * HS; i += blockDim.x) (&hbuf[0][0][0][0])[i] = 0.f;
+  for (int i = threadIdx.x & 255; i < 2 * S * 16 * HS; i += 256) hbuf[i] = 0.f;
+  const float4* wl = wlds + (size_t)wave * NG * NTW * 64 + lane;
+  const float4* bl = blds + (size_t)wave * NTW * 64 + lane;
 
-  const int b0 = blockIdx.x * (16 * S);
-  const float* xrow[S];
+  const int b0 = (blockIdx.x * GRP + grp) * (16 * S);
+  float* xrow[S];
   bool live[S];
 #pragma unroll
   for (int ss = 0; ss < S; ++ss) {
@@ -245,47 +272,62 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(float* __restrict__ x, con
 #pragma unroll
     for (int ss = 0; ss < S; ++ss) c[tt][ss] = 0.f;
 
-  float xb[S][NT], xn[S][NT];
+  // One cell step.  xc holds x_t as B fragments (k-step s <-> units 4 s + q); the fragments of x_{t+1} are requested
+  // into xn right after the input-part MFMAs were issued, a full step ahead of their use.  The time loop below is
+  // unrolled by two with the roles of the two fragment sets swapped, so no register copy ties the loads to their use.
+  // xr: x_t[u] of the lane's own units (residual input); a second, 5-value view of the same rows (L1 hits) -- selecting
+  // them out of the fragment registers by the runtime tile index costs an 18-way v_cndmask chain per value
+  auto step = [&](int t, int cur, float (&xc)[S][NT], float (&xn)[S][NT], float (&xrc)[S][NTW], float (&xrn)[S][NTW]) {
+    // input part (independent of h): acc = b + W_ih x_t
+    f32x4 acc[NTW][S];
 #pragma unroll
-  for (int ss = 0; ss < S; ++ss)
+    for (int tt = 0; tt < NTW; ++tt) {
+      const float4 bv = bl[tt * 64];
 #pragma unroll
-    for (int s = 0; s < NT; ++s) xb[ss][s] = xrow[ss][4 * s];
-  int cur = 0;
-  for (int t = 0; t < L; ++t) {
+      for (int ss = 0; ss < S; ++ss) acc[tt][ss] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float4 wv[NTW];
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) wv[tt] = wl[(g * NTW + tt) * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s = 4 * g + i;
+        if (s < NT) {
+#pragma unroll
+          for (int tt = 0; tt < NTW; ++tt) {
+            const float a = i == 0 ? wv[tt].x : i == 1 ? wv[tt].y : i == 2 ? wv[tt].z : wv[tt].w;
+#pragma unroll
+            for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(a, xc[ss][s], acc[tt][ss]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < L) {
 #pragma unroll
       for (int ss = 0; ss < S; ++ss)
 #pragma unroll
         for (int s = 0; s < NT; ++s) xn[ss][s] = xrow[ss][(size_t)(t + 1) * D + 4 * s];
+#pragma unroll
+      for (int ss = 0; ss < S; ++ss)
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) xrn[ss][tt] = xrow[ss][(size_t)(t + 1) * D + 4 * min(t0 + tt, NT - 1)];
     }
-    // input part (independent of h): acc = b + W_ih x_t
-    f32x4 acc[NTW][S];
-#pragma unroll
-    for (int tt = 0; tt < NTW; ++tt)
-#pragma unroll
-      for (int ss = 0; ss < S; ++ss) acc[tt][ss] = bias[tt];
-#pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-      for (int tt = 0; tt < NTW; ++tt)
-        if (tt < ntw) {
-#pragma unroll
-          for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wi[tt][s], xb[ss][s], acc[tt][ss]);
-        }
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // h_{t-1} of every wave is in hbuf[cur]
     float hb[S][NT];
 #pragma unroll
     for (int ss = 0; ss < S; ++ss)
 #pragma unroll
-      for (int s = 0; s < NT; ++s) hb[ss][s] = hbuf[cur][ss][j][4 * s + q];
+      for (int s = 0; s < NT; ++s) hb[ss][s] = hbuf[((cur * S + ss) * 16 + j) * HS + 4 * s + q];
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt)
-        if (tt < ntw) {
 #pragma unroll
-          for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wh[tt][s], hb[ss][s], acc[tt][ss]);
-        }
+        for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wh[tt][s], hb[ss][s], acc[tt][ss]);
     // cell update, lane-local: (i, f, g, o) = acc[0..3] of unit 4 T + q, sample j
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -297,41 +339,64 @@ __global__ __launch_bounds__(256, 1) void k_lstm_mfma(float* __restrict__ x, con
           const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go = sigmoid_fast(a[3]);
           c[tt][ss] = gf * c[tt][ss] + gi * gg;
           const float h = go * tanh_fast(c[tt][ss]);
-          hbuf[cur ^ 1][ss][j][u] = h;
-          float xres = 0.f;  // x_t[u]: k-step s = t0 + tt of the lane's own fragment
-#pragma unroll
-          for (int s = 0; s < NT; ++s) xres = (s == t0 + tt) ? xb[ss][s] : xres;
-          if (live[ss]) const_cast<float*>(xrow[ss])[(size_t)t * D + 4 * (t0 + tt)] = xres + h;  // x <- x + LSTM(x)
+          hbuf[(((cur ^ 1) * S + ss) * 16 + j) * HS + u] = h;
+          if (live[ss]) xrow[ss][(size_t)t * D + 4 * (t0 + tt)] = xrc[ss][tt] + h;  // x <- x + LSTM(x)
         }
       }
-    cur ^= 1;
+  };
+
+  float xa[S][NT], xb[S][NT], xra[S][NTW], xrb[S][NTW];
 #pragma unroll
-    for (int ss = 0; ss < S; ++ss)
+  for (int ss = 0; ss < S; ++ss) {
 #pragma unroll
-      for (int s = 0; s < NT; ++s) xb[ss][s] = xn[ss][s];
+    for (int s = 0; s < NT; ++s) xa[ss][s] = xrow[ss][4 * s];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) xra[ss][tt] = xrow[ss][4 * min(t0 + tt, NT - 1)];
   }
+  __syncthreads();  // LDS images written
+  for (int t = 0; t < L; t += 2) {
+    step(t, 0, xa, xb, xra, xrb);
+    if (t + 1 < L) step(t + 1, 1, xb, xa, xrb, xra);
+  }
+}
+
+constexpr size_t lstm_mfma_lds(int D, int S, int GRP) {
+  const int NT = D / 4, NTW = (NT + 3) / 4, NG = (NT + 3) / 4;
+  return (size_t)(4 * NG * NTW * 64 + 4 * NTW * 64) * 16 + (size_t)GRP * 2 * S * 16 * (D + 2) * 4;
 }
 
 // batch from which the batch-tiled kernel is faster than one sample per workgroup (measured crossover)
 int g_lstm_mfma_min_batch = 1536;
+int g_lstm_mfma_s = 0;  // 16-sample tiles per workgroup: 0 = by batch, 1, 2
 
 bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
+
+template <int D, int S, int GRP>
+static hipError_t launch_lstm_mfma_t(float* x, const float* wih, const float* whh, const float* bsum, int B, int L,
+                                     hipStream_t s) {
+  constexpr size_t lds = lstm_mfma_lds(D, S, GRP);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_mfma<D, S, GRP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_lstm_mfma<D, S, GRP>), dim3(cdiv(B, 16 * S * GRP)), dim3(256 * GRP), lds, s, x, wih, whh, bsum, B, L);
+  return hipGetLastError();
+}
 
 hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
                             hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  const bool two = B > 16 * 256;  // 32 samples per workgroup once 16-sample tiles exceed the CU count
+  // 16 samples per workgroup (4 waves) while the 16-sample tiles do not exceed the CU count; beyond that 32 samples
+  // per workgroup as two 4-wave groups (ffd_tune "lstm_mfma_s": 1 = 16, 2 = 2 x 16 in eight waves)
+  const bool two = g_lstm_mfma_s ? g_lstm_mfma_s == 2 : B > 16 * 256;
   switch (D) {
-#define X(d)                                                                                                          \
-  case d:                                                                                                             \
-    if (two) hipLaunchKernelGGL((k_lstm_mfma<d, 2>), dim3(cdiv(B, 32)), dim3(256), 0, s, x, wih, whh, bsum, B, L);     \
-    else hipLaunchKernelGGL((k_lstm_mfma<d, 1>), dim3(cdiv(B, 16)), dim3(256), 0, s, x, wih, whh, bsum, B, L);         \
-    break;
+#define X(d) \
+  case d: return two ? launch_lstm_mfma_t<d, 1, 2>(x, wih, whh, bsum, B, L, s) : launch_lstm_mfma_t<d, 1, 1>(x, wih, whh, bsum, B, L, s);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s) {

@@ -89,21 +89,6 @@ class E2CRFCache:
             if self.crf_timestep_history:
                 self.crf_timestep_history.pop(0)
 
-    # caching.py:524-559
-    def compute_event_intensity(self, crf: torch.Tensor, step: int) -> float:
-        prev = self.crf_cache
-        if prev is None:
-            return 0.1 if step > 0 else 1.0
-        a = N.require_gpu_tensor(crf.detach().to(torch.float32).contiguous(), "crf")
-        b = N.require_gpu_tensor(prev.detach().to(torch.float32).contiguous(), "crf_cache")
-        assert a.shape == b.shape
-        rows, D = a.numel() // a.shape[-1], a.shape[-1]
-        work = torch.empty(256, device=a.device, dtype=torch.float32)
-        mean = C.c_double()
-        N.check(N.lib().ffd_row_delta_norm_mean(a.data_ptr(), b.data_ptr(), work.data_ptr(), rows, D, C.byref(mean),
-                                                N.current_stream_ptr(a.device)), None, "ffd_row_delta_norm_mean")
-        return min(1.0, mean.value / self.tau_0)
-
     # caching.py:561-597
     def predict_crf_freqca(self, t_val: float) -> Optional[torch.Tensor]:
         if not self.use_freqca or self.crf_low_cache is None or len(self.crf_high_history) < 2:

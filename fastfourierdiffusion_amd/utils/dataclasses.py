@@ -1,4 +1,4 @@
-"""``fdiff.utils.dataclasses`` mirror (reference: src/fdiff/utils/dataclasses.py:7-31)."""
+"""``fdiff.utils.dataclasses`` mirror (reference: src/fdiff/utils/dataclasses.py:7-18; the training-side collate_batch is out of scope)."""
 from dataclasses import dataclass
 from typing import Optional
 
@@ -17,11 +17,3 @@ class DiffusableBatch:
     @property
     def device(self) -> torch.device:
         return self.X.device
-
-
-def collate_batch(data: list) -> DiffusableBatch:
-    assert "X" in data[0], "The construction of a batch requires a 'X' key."
-    X = torch.stack([example["X"] for example in data])
-    y = torch.stack([example["y"] for example in data]) if "y" in data[0] else None
-    timesteps = torch.stack([example["timestep"] for example in data]) if "timestep" in data[0] else None
-    return DiffusableBatch(X=X, y=y, timesteps=timesteps)

@@ -133,23 +133,3 @@ def predict_hermite(history, timesteps, target_timestep: float, order: int = 2) 
                                      out.numel(), N.current_stream_ptr(stack.device))
     N.check(rc, None, "ffd_hermite_predict")
     return out.to(src_device) if src_device.type != "cuda" else out
-
-
-def hermite_polynomials(s: torch.Tensor, order: int = 2) -> torch.Tensor:
-    """fourier.py:341-394 -- physicists' Hermite polynomials H_0..H_order at ``s`` ((K,) -> (order+1, K);
-    (B, K) -> (order+1, B, K)).  A few host-side scalars (the device path, ``ffd_hermite_predict``, builds its own
-    table in C); kept so that imports of ``fdiff.utils.fourier.hermite_polynomials`` resolve."""
-    was_1d = s.dim() == 1
-    if was_1d:
-        s = s.unsqueeze(0)
-    H = [torch.ones_like(s)]
-    if order >= 1:
-        H.append(2 * s)
-    if order >= 2:
-        H.append(4 * s ** 2 - 2)
-    if order >= 3:
-        H.append(8 * s ** 3 - 12 * s)
-    for n in range(3, order):
-        H.append(2 * s * H[n] - 2 * n * H[n - 1])
-    out = torch.stack(H[: order + 1], dim=0)
-    return out.squeeze(1) if was_1d else out

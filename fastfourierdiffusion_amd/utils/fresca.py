@@ -58,71 +58,3 @@ def apply_fresca_to_score(score: torch.Tensor, low_scale: float = 1.0, high_scal
     return frequency_scale(score, low_scale=low_scale,
                            high_scale=dynamic_high_scale(high_scale, timestep, num_steps),
                            cutoff_ratio=cutoff_ratio, cutoff_strategy=cutoff_strategy)
-
-
-def create_frequency_masks(shape, cutoff_ratio: float, cutoff_strategy: str = "spatial",
-                           freq_spectrum: Optional[torch.Tensor] = None):
-    """fresca.py:13-108 -- (low_pass_mask, high_pass_mask) for a 1-D (n_freq,) or 2-D (H, W) frequency grid.
-    Host-side helper on a handful of elements (the sampling path computes its cutoff on the device, csrc/ffd_fft.hip);
-    restated here so that code importing it from ``fdiff.utils.fresca`` keeps working."""
-    device = freq_spectrum.device if freq_spectrum is not None else torch.device("cpu")
-    if len(shape) == 1:
-        n_freq = shape[0]
-        k = torch.arange(n_freq, device=device).float()
-        if cutoff_strategy == "spatial":
-            low = (k <= cutoff_ratio * n_freq).float()
-        elif cutoff_strategy == "energy":
-            if freq_spectrum is None:
-                raise ValueError("freq_spectrum required for energy-based cutoff")
-            etot = torch.abs(freq_spectrum).sum()
-            rc, cum = 0, 0.0
-            for i in range(n_freq):
-                cum += torch.abs(freq_spectrum[i]).item()
-                if cum >= cutoff_ratio * etot.item():
-                    rc = i
-                    break
-            low = (k <= rc).float()
-        else:
-            raise ValueError(f"Unknown cutoff_strategy: {cutoff_strategy}")
-    elif len(shape) == 2:
-        H, W = shape
-        kx = torch.arange(H, device=device, dtype=torch.float32)
-        ky = torch.arange(W, device=device, dtype=torch.float32)
-        kx, ky = torch.meshgrid(kx, ky, indexing="ij")
-        k_dist = torch.sqrt(kx ** 2 + ky ** 2)
-        if cutoff_strategy == "spatial":
-            low = (k_dist <= cutoff_ratio * min(H / 2, W / 2)).float()
-        elif cutoff_strategy == "energy":
-            if freq_spectrum is None:
-                raise ValueError("freq_spectrum required for energy-based cutoff")
-            etot = torch.abs(freq_spectrum).sum()
-            rc = 0
-            for R in range(int(min(H, W) / 2) + 1):
-                if (torch.abs(freq_spectrum) * (k_dist <= R).float()).sum() >= cutoff_ratio * etot:
-                    rc = R
-                    break
-            low = (k_dist <= rc).float()
-        else:
-            raise ValueError(f"Unknown cutoff_strategy: {cutoff_strategy}")
-    else:
-        raise ValueError(f"Unsupported shape dimension: {len(shape)}")
-    return low, 1.0 - low
-
-
-def analyze_frequency_content(x: torch.Tensor, cutoff_ratio: float = 0.5) -> dict:
-    """fresca.py:271-311 -- band energies of |rfft(x)|.  The magnitudes come from the device (packed dft ->
-    spectral density); the mask algebra repeats the reference's own broadcasting, including its (n_freq, 1) 2-D mask
-    (only the DC bin is "low") and its shape error for batch sizes other than 1 or n_freq."""
-    from .fourier import spectral_density
-
-    mag = torch.sqrt(spectral_density(x, apply_dft=True))  # (B, n_freq, C) = |rfft(x, norm="ortho")|
-    n_freq = mag.shape[1]
-    low_mask, high_mask = create_frequency_masks((n_freq, 1), cutoff_ratio, "spatial")
-    low_mask = low_mask.unsqueeze(0).unsqueeze(-1).to(x.device)
-    high_mask = high_mask.unsqueeze(0).unsqueeze(-1).to(x.device)
-    low_energy = (mag * low_mask).sum()
-    high_energy = (mag * high_mask).sum()
-    total_energy = mag.sum()
-    return {"low_energy": low_energy, "high_energy": high_energy, "total_energy": total_energy,
-            "low_energy_ratio": low_energy / (total_energy + 1e-8),
-            "high_energy_ratio": high_energy / (total_energy + 1e-8)}

@@ -235,12 +235,6 @@ int ffd_hermite_predict(const float* history, const double* timesteps, double ta
  * callers with time-domain input run ffd_dft first (apply_dft=True). */
 int ffd_spectral_density(const float* xf, float* out, int B, int L, int C, void* stream);
 
-/* The reduction of E2CRFCache.compute_event_intensity (caching.py:546-556): *mean_out = mean over the `rows` rows of
- * || a_r - b_r ||_2 for two device tensors (rows, D).  `work` = 256 device floats.  Synchronises `stream` (the
- * reference reads the value with .item()). */
-int ffd_row_delta_norm_mean(const float* a, const float* b, float* work, int rows, int D, double* mean_out,
-                            void* stream);
-
 /* CRF capture inside ffd_sample_batch (the reference's cache.update_crf call, sampler.py:70-73):
  * on cached steps whose global step g satisfies g % every == 0 the (NL, L, d) CRF (score_models.py:181-194)
  * is written to ring slot (g / every) % n_slots; `last` receives the CRF of the last step of each
@@ -292,16 +286,16 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
 /* Process-wide tuning knobs for experiments and for the test suite's kernel variants (results stay within the
  * parity tolerance, only the kernel choice / tiling changes):
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
+ *   "ffn_persist" = 1 | 0 | n                  fused FFN at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
  *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
  *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
+ *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
- *   "fuse_layer" = -1 (auto) | 0 | 1           out-proj+LN1+FFN+LN2+next-QKV in one launch (k_layer; default 0);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;
- *   "attn_impl" = 0 | 1 | 2 | 3                two-kernel path only: hybrid MFMA/VALU, all VALU, 4x4x1 MFMA, packed fp32;
  *   "attn_qg" = 0 (heuristic) | 1 | 2 | 3      query tiles per wave;
- *   "bench_kernel" = 0 | 1 | 2                 what ffd_bench_ffn times (FFN, k_layer without / with the QKV epilogue). */
+ */
 int ffd_tune(const char* key, int value);
 
 /* ---- introspection for benchmarks --------------------------------------- */
@@ -338,6 +332,12 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
  * on `stream` with HIP events; returns average milliseconds per launch in *ms_out.
  * Synchronous (benchmark helper only). */
 int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream);
+
+/* Diagnostic: the shader clock the chip holds under the dominant kernel.  Launches the fused FFN back to back for
+ * `warm_seconds` on random data, then once more with in-kernel stamps (s_memtime / s_memrealtime around the main loop
+ * of every workgroup, written to a scratch buffer nothing else reads); *ghz_out = median over workgroups of
+ * shader cycles per 10 ns tick x 0.1, *loop_us_out (may be NULL) = median main-loop duration.  Synchronous. */
+int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out, void* stream);
 
 #ifdef __cplusplus
 }

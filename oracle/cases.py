@@ -163,16 +163,6 @@ EXTRA_TRAJ_CASES = [
          use_cache=True, cache_kwargs={}, wseed=43, zseed=74),
 ]
 
-# create_frequency_masks / analyze_frequency_content (fresca.py:13-108, 271-311).  (name, shape, ratio, strategy, spectrum seed or None)
-MASK_CASES = [
-    ("m1_spatial", (94,), 0.5, "spatial", None),
-    ("m1_energy", (94,), 0.6, "energy", 101),
-    ("m1_energy_small", (11,), 0.05, "energy", 102),
-    ("m2_spatial", (12, 9), 0.5, "spatial", None),
-    ("m2_energy", (10, 14), 0.4, "energy", 103),
-]
-ANALYZE_CASES = [("an_ecg", 1, 187, 1, 111, 0.5), ("an_b_eq_nf", 51, 100, 3, 112, 0.3)]  # (name, B, L, C, seed, ratio)
-
 
 # ---- round 2 (g12) -----------------------------------------------------------------------------------
 # ScoreModule.forward with PER-SAMPLE timesteps (time_encoder(X, timesteps), score_models.py:102); "int" = the

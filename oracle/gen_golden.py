@@ -154,16 +154,6 @@ def gen_extra_traj(ns) -> None:
         g[c["name"]] = out.numpy()
         g[c["name"] + "_ts"] = sch.timesteps.numpy().copy()
         print(c["name"], out.shape, float(out.abs().max()))
-    from fdiff.utils import fresca as rfresca
-    for (name, shape, ratio, strat, seed) in cases.MASK_CASES:
-        spec = None if seed is None else torch.from_numpy(np.abs(next(synthetic.noise_stream(shape, 1, seed))))
-        lo, hi = rfresca.create_frequency_masks(shape, ratio, strat, spec)
-        g[name + "_low"], g[name + "_high"] = lo.numpy(), hi.numpy()
-    for (name, B, L, C, seed, ratio) in cases.ANALYZE_CASES:
-        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, seed)))
-        r = rfresca.analyze_frequency_content(x, ratio)
-        g[name] = np.array([float(r[k]) for k in ("low_energy", "high_energy", "total_energy", "low_energy_ratio",
-                                                  "high_energy_ratio")], dtype=np.float64)
     np.savez_compressed(os.path.join(OUT, "g11_extra_traj.npz"), **g)
 
 

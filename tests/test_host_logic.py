@@ -108,7 +108,7 @@ def test_fdiff_surface_and_state_dict_keys():
     from fdiff.sampling.sampler import DiffusionSampler
     from fdiff.schedulers.sde import SDE, VEScheduler, VPScheduler
     from fdiff.utils.caching import E2CRFCache
-    from fdiff.utils.dataclasses import DiffusableBatch, collate_batch
+    from fdiff.utils.dataclasses import DiffusableBatch
     from fdiff.utils.fourier import dft, idft  # noqa: F401
     from fastfourierdiffusion_amd.utils import synthetic
 
@@ -144,8 +144,8 @@ def test_fdiff_surface_and_state_dict_keys():
                                               "current_step"}
     m.disable_caching()
     assert m.cache is None and not m.use_cache
-    b = collate_batch([{"X": torch.zeros(5, 2), "timestep": torch.tensor(0.5)} for _ in range(3)])
-    assert isinstance(b, DiffusableBatch) and len(b) == 3 and b.device.type == "cpu"
+    b = DiffusableBatch(X=torch.zeros(3, 5, 2), y=None, timesteps=torch.full((3,), 0.5))
+    assert len(b) == 3 and b.device.type == "cpu"
     ve = VEScheduler(sigma_min=0.01, sigma_max=2)
     assert ve.sigma_max == 2 and ve.noise_scaling is False
     del s2
@@ -319,43 +319,6 @@ def test_bench_self_launcher_relays_rank0_and_fails_on_child_failure(tmp_path, m
     monkeypatch.setenv("FAIL_RANK", "2")
     with contextlib.redirect_stdout(io.StringIO()):
         assert bench.self_launch(args, ["--gpus", "3"]) != 0
-
-
-def test_create_frequency_masks_golden():
-    """fresca.py:13-108: pure host helper of the fdiff.utils.fresca mirror, pinned against the reference (g11)."""
-    import numpy as np
-    import torch
-
-    from conftest import load_golden
-    from fastfourierdiffusion_amd.utils import synthetic
-    from fastfourierdiffusion_amd.utils.fresca import create_frequency_masks
-    from oracle import cases
-
-    g = load_golden("g11_extra_traj.npz")
-    for (name, shape, ratio, strat, seed) in cases.MASK_CASES:
-        spec = None if seed is None else torch.from_numpy(np.abs(next(synthetic.noise_stream(shape, 1, seed))))
-        lo, hi = create_frequency_masks(shape, ratio, strat, spec)
-        np.testing.assert_array_equal(lo.numpy(), g[name + "_low"])
-        np.testing.assert_array_equal(hi.numpy(), g[name + "_high"])
-    with pytest.raises(ValueError):
-        create_frequency_masks((8,), 0.5, "energy", None)
-    with pytest.raises(ValueError):
-        create_frequency_masks((2, 2, 2), 0.5)
-
-
-def test_hermite_polynomials_known_answers():
-    """fourier.py:341-394: H0 = 1, H1 = 2s, H2 = 4s^2 - 2, H3 = 8s^3 - 12s, then H_{n+1} = 2s H_n - 2n H_{n-1}."""
-    from fastfourierdiffusion_amd.utils.fourier import hermite_polynomials
-
-    s = torch.tensor([-1.0, -0.5, 0.0, 0.25, 1.0])
-    H = hermite_polynomials(s, 4)
-    assert H.shape == (5, 5)
-    torch.testing.assert_close(H[0], torch.ones(5))
-    torch.testing.assert_close(H[1], 2 * s)
-    torch.testing.assert_close(H[2], 4 * s ** 2 - 2)
-    torch.testing.assert_close(H[3], 8 * s ** 3 - 12 * s)
-    torch.testing.assert_close(H[4], 16 * s ** 4 - 48 * s ** 2 + 12)
-    assert hermite_polynomials(torch.zeros(2, 3), 2).shape == (3, 2, 3)
 
 
 def test_hydra_surface_targets_resolve_and_instantiate():

@@ -3,11 +3,10 @@ import ctypes as C, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 from fastfourierdiffusion_amd import _native as N
-kern = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+kern = 0
 vals = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 200, 400, 800, 1200]
 model, sch, sd = bench.build_model(torch.device("cuda", 0), "ecg")
 ctx = model._ctx(); lib = ctx.lib
-lib.ffd_tune(b"bench_kernel", kern)
 res = {v: [] for v in vals}
 for rnd in range(4):
     for v in vals:
