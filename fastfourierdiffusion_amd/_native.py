@@ -104,7 +104,8 @@ SIGNATURES = {
     "ffd_cache_configure": (C.c_int, [_P, C.POINTER(CacheCfg)]),
     "ffd_tune": (C.c_int, [C.c_char_p, C.c_int]),
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
-    "ffd_probe_ffn_clock": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), _P]),
+    "ffd_probe_ffn_clock": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int), _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1233,7 +1233,7 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
 }
 
 int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out,
-                        void* stream) {
+                        unsigned long long* raw_out, int raw_capacity, int* nwg_out, void* stream) {
   if (!ctx) return FFD_ERR_INVALID;
   int rc = check_ready(ctx, B);
   if (rc) return rc;
@@ -1246,10 +1246,10 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);  // random data
   HIPCHECK(hipGetLastError());
-  const int nwg = cdiv(M, ffn_tile_rows(M));
+  const int nwg = cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
   unsigned long long* stamps = nullptr;
-  HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 2 * nwg));
-  HIPCHECK(hipMemsetAsync(stamps, 0, sizeof(unsigned long long) * 2 * nwg, s));
+  HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 8 * nwg));
+  HIPCHECK(hipMemsetAsync(stamps, 0, sizeof(unsigned long long) * 8 * nwg, s));
   // back-to-back launches for warm_seconds (the clock the chip settles at under this load), then the stamped one
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
@@ -1265,18 +1265,22 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
     elapsed = ms * 1e-3;
   }
   HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, stamps));
-  std::vector<unsigned long long> h(2 * (size_t)nwg);
-  HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 2 * nwg, hipMemcpyDeviceToHost, s));
+  std::vector<unsigned long long> h(8 * (size_t)nwg);
+  HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));
   (void)hipFree(stamps);
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   std::vector<double> ghz, us;
+  int used = 0;
   for (int i = 0; i < nwg; ++i)
-    if (h[2 * i + 1] > 0) {
-      ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1);  // shader cycles per 10 ns tick
-      us.push_back((double)h[2 * i + 1] * 0.01);
+    if (h[8 * i + 1] > 0) {
+      ghz.push_back((double)h[8 * i] / (double)h[8 * i + 1] * 0.1);  // shader cycles per 10 ns tick
+      us.push_back((double)h[8 * i + 1] * 0.01);
+      if (raw_out && used < raw_capacity) memcpy(raw_out + 8 * (size_t)used, &h[8 * i], sizeof(unsigned long long) * 8);
+      ++used;
     }
+  if (nwg_out) *nwg_out = used;
   if (ghz.empty()) return ctx->fail(FFD_ERR_STATE, "no stamps were written");
   std::sort(ghz.begin(), ghz.end());
   std::sort(us.begin(), us.end());

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     if (hwid & 1)
       for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
   }
-  unsigned long long st_clk = 0, st_rt = 0, st_acc = 0, st_acc_rt = 0;
+  // stamp record of a workgroup (8 x u64): [0] sum of shader-clock deltas over its main loops, [1] the same in 10 ns
+  // real-time ticks, [2] real time at entry, [3] / [4] begin / end of its first main loop, [5] end of its first
+  // epilogue, [6] exit, [7] tiles processed.  s_memrealtime is one chip-wide 100 MHz counter: a launch timeline.
+  unsigned long long st_clk = 0, st_rt = 0, st_acc = 0, st_acc_rt = 0, st_first_b = 0, st_first_e = 0, st_epi = 0;
+  const unsigned long long st_entry = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  int st_tiles = 0;
 
   for (;;) {  // tiles of this workgroup (a single iteration unless DMA)
     float* xs = xsb + buf * R * SX;
@@ -169,7 +174,10 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (stamp) st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();  // scalar: stays in SGPRs
+    if (stamp) {  // scalar: stays in SGPRs
+      st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
+      if (st_tiles == 0) st_first_b = st_rt;
+    }
     for (int ci = 0; ci < nchunk; ++ci) {
       const int nx = (ci + 1 < nchunk) ? ci + 1 : 0;  // the last prefetch wraps to chunk 0 = the next tile's first chunk
       // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
@@ -218,8 +226,10 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
       __builtin_amdgcn_sched_barrier(0);
     }
     if (stamp) {
+      const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
       st_acc += __builtin_amdgcn_s_memtime() - st_clk;
-      st_acc_rt += __builtin_amdgcn_s_memrealtime() - st_rt;
+      st_acc_rt += rt - st_rt;
+      if (st_tiles == 0) st_first_e = rt;
     }
 
     // ---- deterministic cross-wave reduction through LDS, fixed order of additions:
@@ -319,6 +329,10 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
         if (c < D) Y[(size_t)m * D + c] = (vals[i] - mean) * rstd * gam[c] + bet[c];
       }
     }
+    if (stamp) {
+      if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
+      ++st_tiles;
+    }
     if (!DMA || tile_next >= ntiles) break;
     tile = tile_next;
     buf ^= 1;
@@ -326,8 +340,9 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     //  writes: the images alternate, and `red` is next written after that barrier)
   }
   if (stamp && threadIdx.x == 0) {
-    stamp[2 * blockIdx.x] = st_acc;
-    stamp[2 * blockIdx.x + 1] = st_acc_rt;
+    unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
+    o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
+    o[6] = __builtin_amdgcn_s_memrealtime(), o[7] = (unsigned long long)st_tiles;
   }
 }
 

@@ -262,6 +262,32 @@ struct Pow2Plan {
   int radix[12];
 };
 
+// radices of the N-point complex transform, N = 2^e; radix 8 last (the last pass has unit twiddles)
+constexpr __host__ __device__ Pow2Plan pow2_plan(int N) {
+  Pow2Plan p{};
+  int e = 0;
+  while ((1 << e) < N) ++e;
+  const int r = e % 3;
+  if (r == 1 && e >= 4) {
+    p.radix[p.npass++] = 4;
+    p.radix[p.npass++] = 4;
+    e -= 4;
+  } else if (r == 1) {
+    p.radix[p.npass++] = 2;
+    e -= 1;
+  } else if (r == 2) {
+    p.radix[p.npass++] = 4;
+    e -= 2;
+  }
+  for (; e > 0; e -= 3) p.radix[p.npass++] = 8;
+  return p;
+}
+constexpr __host__ __device__ int ilog2c(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
 template <bool INV>
 __device__ __forceinline__ float2 mul_mi(float2 a) {  // a * (-i) forward, a * (+i) inverse
   return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
@@ -351,6 +377,25 @@ __device__ __forceinline__ float2* pow2_fft(float2* x, float2* y, const float2* 
     y = tmp;
   }
   return x;
+}
+
+// The same transform with N (and so the radix plan and every stride) a compile-time constant: the passes unroll.
+template <bool INV, int N, int LS, int LM>
+__device__ __forceinline__ float2* pow2_fft_static(float2* x, float2* y, const float2* T, int CG, int cg, int lc) {
+  if constexpr (LM == 0) {
+    return x;
+  } else {
+    constexpr int LR = (LM % 3 == 0) ? 3 : (LM % 3 == 2) ? 2 : (LM >= 4 ? 2 : 1);  // pow2_plan's order
+    pow2_pass<(1 << LR), INV>(x, y, T, N, LS, LM - LR, CG, cg, lc);
+    return pow2_fft_static<INV, N, LS + LR, LM - LR>(y, x, T, CG, cg, lc);
+  }
+}
+
+template <bool INV, int LT>
+__device__ __forceinline__ float2* pow2_fft_any(float2* x, float2* y, const float2* T, const Pow2Plan& plan, int N, int CG,
+                                                int cg, int lc) {
+  if constexpr (LT != 0) return pow2_fft_static<INV, LT / 2, 0, ilog2c(LT / 2)>(x, y, T, CG, cg, lc);
+  else return pow2_fft<INV>(x, y, T, plan, N, CG, cg, lc);
 }
 
 // Z (N x CG complex) -> packed ortho spectrum rows (L x CG floats) in `st`, scaled by sc.
@@ -490,11 +535,23 @@ __device__ __forceinline__ void pow2_store_time(const float2* __restrict__ z, fl
 //   forward : out = (dft(x) - a0) / a1                    (datamodules.py:42-43,61-62; a0 = mean, a1 = std, (L, C))
 //   inverse : out = idft(x * a0 + a1)                     (cmd/sample.py:107-113;     a0 = std,  a1 = mean)
 // each product / sum rounded separately like the reference's tensor ops.
-template <bool INVERSE, bool VEC>
+// LT / CT != 0: the slab shape (L = LT, C = CG = CT) is a compile-time constant -- every index split is a shift by a
+// literal, the radix plan unrolls, the trip counts are known.  The generic instance (0, 0) spends most of its issue
+// slots on integer address arithmetic (64-bit multiplies by runtime strides): 65 us vs the config-5 shard's 45 us
+// of HBM time.  (512, 8) is the BASELINE configs[4] shape.
+#define FFD_POW2_SHAPE                                            \
+  const int L = LT ? LT : L_;                                     \
+  const int C = CT ? CT : C_;                                     \
+  const int CG = CT ? CT : CG_;                                   \
+  const int lc = CT ? ilog2c(CT) : lc_;                           \
+  const Pow2Plan plan = LT ? pow2_plan(LT / 2) : plan_;
+
+template <bool INVERSE, bool VEC, int LT, int CT>
 __global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in, float* __restrict__ out,
-                                                   const float2* __restrict__ Wg, Pow2Plan plan, int B, int L, int C,
-                                                   int CG, int lc, float scale, const float* __restrict__ a0,
+                                                   const float2* __restrict__ Wg, Pow2Plan plan_, int B, int L_, int C_,
+                                                   int CG_, int lc_, float scale, const float* __restrict__ a0,
                                                    const float* __restrict__ a1) {
+  FFD_POW2_SHAPE
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;                 // L twiddles
@@ -514,7 +571,7 @@ __global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in,
     if (!INVERSE) {
       pow2_load_time<VEC>(src, bufA, L, C, c0, CG, cg, pf, pre);  // (barrier inside; also covers the twiddle table)
       if (pf && bn < B) slab_prefetch(in + (size_t)bn * L * C, n4, pre);
-      float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+      float2* Z = pow2_fft_any<false, LT>(bufA, bufB, T, plan, N, CG, cg, lc);
       float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
       pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
       if (VEC) {
@@ -571,7 +628,7 @@ __global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in,
       __syncthreads();
       if (pf && bn < B) slab_prefetch(in + (size_t)bn * L * C, n4, pre);
       pow2_split_inv(st, bufA, T, N, CG, cg, lc);
-      float2* z = pow2_fft<true>(bufA, bufB, T, plan, N, CG, cg, lc);
+      float2* z = pow2_fft_any<true, LT>(bufA, bufB, T, plan, N, CG, cg, lc);
       pow2_store_time<VEC>(z, dst, L, C, c0, CG, cg, scale);
     }
     __syncthreads();  // the LDS images are rewritten by the next sample
@@ -579,10 +636,11 @@ __global__ __launch_bounds__(256) void k_rfft_pow2(const float* __restrict__ in,
 }
 
 // FreSca on the power-of-two path: per-sample |X_k| partial sums, and FFT -> per-bin scale -> inverse FFT.
-template <bool VEC>
+template <bool VEC, int LT, int CT>
 __global__ __launch_bounds__(256) void k_fresca_spectrum_pow2(const float* __restrict__ in, float* __restrict__ partial,
-                                                              const float2* __restrict__ Wg, Pow2Plan plan, int B, int L,
-                                                              int C, int CG, int lc, float scale) {
+                                                              const float2* __restrict__ Wg, Pow2Plan plan_, int B, int L_,
+                                                              int C_, int CG_, int lc_, float scale) {
+  FFD_POW2_SHAPE
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;
@@ -597,7 +655,7 @@ __global__ __launch_bounds__(256) void k_fresca_spectrum_pow2(const float* __res
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg, pf, pre);
     if (pf && b + (int)gridDim.x < B) slab_prefetch(in + (size_t)(b + gridDim.x) * L * C, n4, pre);
-    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+    float2* Z = pow2_fft_any<false, LT>(bufA, bufB, T, plan, N, CG, cg, lc);
     float* st = reinterpret_cast<float*>(Z == bufA ? bufB : bufA);
     pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
     const int nf = N + 1;
@@ -614,11 +672,12 @@ __global__ __launch_bounds__(256) void k_fresca_spectrum_pow2(const float* __res
   }
 }
 
-template <bool VEC>
+template <bool VEC, int LT, int CT>
 __global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restrict__ in, float* __restrict__ out,
-                                                           const float2* __restrict__ Wg, Pow2Plan plan, int B, int L,
-                                                           int C, int CG, int lc, const int* __restrict__ rc_dev,
+                                                           const float2* __restrict__ Wg, Pow2Plan plan_, int B, int L_,
+                                                           int C_, int CG_, int lc_, const int* __restrict__ rc_dev,
                                                            float rc_host, float low, float high, float scale) {
+  FFD_POW2_SHAPE
   extern __shared__ __align__(16) float2 sm[];
   const int N = L >> 1;
   float2* T = sm;
@@ -635,7 +694,7 @@ __global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restri
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     pow2_load_time<VEC>(in + (size_t)b * L * C, bufA, L, C, c0, CG, cg, pf, pre);
     if (pf && b + (int)gridDim.x < B) slab_prefetch(in + (size_t)(b + gridDim.x) * L * C, n4, pre);
-    float2* Z = pow2_fft<false>(bufA, bufB, T, plan, N, CG, cg, lc);
+    float2* Z = pow2_fft_any<false, LT>(bufA, bufB, T, plan, N, CG, cg, lc);
     float2* other = (Z == bufA) ? bufB : bufA;
     float* st = reinterpret_cast<float*>(other);
     pow2_split_fwd(Z, st, T, N, CG, cg, lc, scale);
@@ -657,7 +716,7 @@ __global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restri
     }
     __syncthreads();
     pow2_split_inv(st, Z, T, N, CG, cg, lc);
-    float2* z = pow2_fft<true>(Z, other, T, plan, N, CG, cg, lc);
+    float2* z = pow2_fft_any<true, LT>(Z, other, T, plan, N, CG, cg, lc);
     pow2_store_time<VEC>(z, out + (size_t)b * L * C, L, C, c0, CG, cg, scale);
     __syncthreads();
   }
@@ -665,17 +724,7 @@ __global__ __launch_bounds__(256) void k_fresca_apply_pow2(const float* __restri
 
 static bool is_pow2(int L) { return L >= 2 && (L & (L - 1)) == 0; }
 
-static Pow2Plan make_pow2_plan(int N) {  // radices of the N-point complex transform, N = 2^e; radix 8 last
-  Pow2Plan p{};
-  int e = 0;
-  while ((1 << e) < N) ++e;
-  const int r = e % 3;
-  if (r == 1 && e >= 4) p.radix[p.npass++] = 4, p.radix[p.npass++] = 4, e -= 4;
-  else if (r == 1) p.radix[p.npass++] = 2, e -= 1;
-  else if (r == 2) p.radix[p.npass++] = 4, e -= 2;
-  for (; e > 0; e -= 3) p.radix[p.npass++] = 8;
-  return p;
-}
+static Pow2Plan make_pow2_plan(int N) { return pow2_plan(N); }
 
 // channels per workgroup and LDS bytes of the power-of-two path: the whole slab when it fits
 // (<= 64 KiB keeps several workgroups on a CU; up to the CU's 160 KiB before the channels are split)
@@ -774,15 +823,17 @@ hipError_t launch_dft(const float* in, float* out, int B, int L, int C, int inve
     const int lc = ceil_log2(CG);
     const bool vec = CG == C && C % 4 == 0 && aligned16(in) && aligned16(out) && aligned16(a0) && aligned16(a1);
     dim3 grid(persistent_blocks(B, lds), cdiv(C, CG)), block(256);
-#define FFD_RFFT(INV, VEC)                                                                                   \
+#define FFD_RFFT(INV, VEC, LT, CT)                                                                           \
   do {                                                                                                       \
-    if ((e = allow_lds(k_rfft_pow2<INV, VEC>, lds)) != hipSuccess) return e;                                 \
-    hipLaunchKernelGGL((k_rfft_pow2<INV, VEC>), grid, block, lds, s, in, out, W, plan, B, L, C, CG, lc, scale, a0, a1); \
+    if ((e = allow_lds(k_rfft_pow2<INV, VEC, LT, CT>, lds)) != hipSuccess) return e;                         \
+    hipLaunchKernelGGL((k_rfft_pow2<INV, VEC, LT, CT>), grid, block, lds, s, in, out, W, plan, B, L, C, CG, lc, scale, a0, \
+                       a1);                                                                                  \
   } while (0)
+    const bool shard = vec && L == 512 && C == 8;  // the config-5 shape has its own instance
     if (inverse) {
-      if (vec) FFD_RFFT(true, true); else FFD_RFFT(true, false);
+      if (shard) FFD_RFFT(true, true, 512, 8); else if (vec) FFD_RFFT(true, true, 0, 0); else FFD_RFFT(true, false, 0, 0);
     } else {
-      if (vec) FFD_RFFT(false, true); else FFD_RFFT(false, false);
+      if (shard) FFD_RFFT(false, true, 512, 8); else if (vec) FFD_RFFT(false, true, 0, 0); else FFD_RFFT(false, false, 0, 0);
     }
 #undef FFD_RFFT
     return hipGetLastError();
@@ -838,14 +889,18 @@ static hipError_t launch_fresca_apply(const float* in, float* out, const float2*
   if (g.pow2) {
     const bool vec = g.CG == C && C % 4 == 0 && aligned16(in) && aligned16(out);
     grid.x = persistent_blocks(B, g.lds);
-    if (vec) {
-      if ((e = allow_lds(k_fresca_apply_pow2<true>, g.lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_fresca_apply_pow2<true>, grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc, rc_dev,
-                         rc_host, low, high, sc);
+    if (vec && L == 512 && C == 8) {
+      if ((e = allow_lds(k_fresca_apply_pow2<true, 512, 8>, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_fresca_apply_pow2<true, 512, 8>), grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG,
+                         g.lc, rc_dev, rc_host, low, high, sc);
+    } else if (vec) {
+      if ((e = allow_lds(k_fresca_apply_pow2<true, 0, 0>, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_fresca_apply_pow2<true, 0, 0>), grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc,
+                         rc_dev, rc_host, low, high, sc);
     } else {
-      if ((e = allow_lds(k_fresca_apply_pow2<false>, g.lds)) != hipSuccess) return e;
-      hipLaunchKernelGGL(k_fresca_apply_pow2<false>, grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc, rc_dev,
-                         rc_host, low, high, sc);
+      if ((e = allow_lds(k_fresca_apply_pow2<false, 0, 0>, g.lds)) != hipSuccess) return e;
+      hipLaunchKernelGGL((k_fresca_apply_pow2<false, 0, 0>), grid, block, g.lds, s, in, out, W, g.plan2, B, L, C, g.CG, g.lc,
+                         rc_dev, rc_host, low, high, sc);
     }
   } else {
     if ((e = allow_lds(k_fresca_apply, g.lds)) != hipSuccess) return e;
@@ -875,12 +930,19 @@ hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L,
     dim3 grid(B, NGc), block(256);
     if (g.pow2) {
       grid.x = persistent_blocks(B, g.lds);
-      if (g.CG == C && C % 4 == 0 && aligned16(in)) {
-        if ((e = allow_lds(k_fresca_spectrum_pow2<true>, g.lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fresca_spectrum_pow2<true>, grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG, g.lc, sc);
+      const bool vec = g.CG == C && C % 4 == 0 && aligned16(in);
+      if (vec && L == 512 && C == 8) {
+        if ((e = allow_lds(k_fresca_spectrum_pow2<true, 512, 8>, g.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fresca_spectrum_pow2<true, 512, 8>), grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C,
+                           g.CG, g.lc, sc);
+      } else if (vec) {
+        if ((e = allow_lds(k_fresca_spectrum_pow2<true, 0, 0>, g.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fresca_spectrum_pow2<true, 0, 0>), grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG,
+                           g.lc, sc);
       } else {
-        if ((e = allow_lds(k_fresca_spectrum_pow2<false>, g.lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fresca_spectrum_pow2<false>, grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG, g.lc, sc);
+        if ((e = allow_lds(k_fresca_spectrum_pow2<false, 0, 0>, g.lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_fresca_spectrum_pow2<false, 0, 0>), grid, block, g.lds, s, in, partial, W, g.plan2, B, L, C, g.CG,
+                           g.lc, sc);
       }
     } else {
       if ((e = allow_lds(k_fresca_spectrum, g.lds)) != hipSuccess) return e;

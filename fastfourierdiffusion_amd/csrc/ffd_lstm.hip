@@ -186,48 +186,56 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
 // ---------------------------------------------------------------------------
 // Large batches: batch-tiled recurrence on the exact-fp32 matrix core, input gates fused.
 //
-// A workgroup (4 waves, one per SIMD) owns 16 S samples for the whole sequence.  Per cell step the gate
-// pre-activations of a 16-sample tile are  G^T (4d x 16) = W_ih x_t^T + W_hh h_{t-1}^T + b  on
-// v_mfma_f32_16x16x4_f32 with the WEIGHTS as the A operand, resident in VGPRs for all L steps (each wave keeps the
-// fragments of its own 16-row tiles: 2 x 5 x 18 registers at d = 72), so neither W_ih nor W_hh is ever re-read and
-// the (B, L, 4d) gate tensor of the small-batch path (185 MB per 512 samples and layer) never exists.
+// A group of 4 waves (one per SIMD) owns 16 samples for the whole sequence; a workgroup holds GRP such groups.  Per
+// cell step the gate pre-activations of the 16-sample tile are
+//     G^T (4d x 16) = W_ih x_t^T + W_hh h_{t-1}^T + b          on v_mfma_f32_16x16x4_f32
+// with the WEIGHTS as the A operand: each wave keeps the W_hh fragments of its own 16-row tiles in VGPRs for all L
+// steps (5 x 18 registers at d = 72; biases too) and streams its W_ih fragments from a wave-private LDS image (one ds_read_b128
+// per 4 k-steps) -- neither matrix is re-read from memory, and the (B, L, 4d) gate tensor of the small-batch path
+// (185 MB per 512 samples and layer) never exists.
 // Row order inside a 16-row tile is (unit, gate) = (i >> 2, i & 3): the accumulator D[i = 4 (l >> 4) + r][j = l & 15]
 // then leaves lane l with all FOUR gates (r = i, f, g, o) of unit 4 T + (l >> 4) for sample (l & 15) -- the cell update
-// is lane-local, c lives in a register, and the new h of unit 4 T + q sits in the lane that, as the B operand of
-// k-step s = T, must supply h[sample j][k = 4 s + q]: the same lane.  Waves own disjoint unit tiles, so h is exchanged
-// through a double-buffered LDS image (one barrier per cell step); x_t fragments come straight from global memory
-// (prefetched one step ahead; the four waves share the rows through L1) and double as the residual input.
-// 18 tiles over 4 waves split 5 / 5 / 4 / 4: the matrix pipe of the 5-tile SIMDs paces the step.
+// is lane-local and c lives in a register.  Waves own disjoint unit tiles (18 tiles over 4 waves: 5 / 5 / 4 / 4; the
+// 4-tile waves run a phantom tile on zero weights, the step is paced by the 5-tile SIMDs anyway), so h is exchanged
+// through a double-buffered LDS image with one rendezvous per step.
+// x_t never travels as fragments: the group's 256 threads move the tile's 16 rows (16 x d floats) per step as whole
+// float4 -- HBM -> registers three steps ahead, registers -> a 3-slot ring of LDS row images two steps ahead, B fragments
+// from the image like h -- and write x_t + h_t back the same way one step later (x_t from its ring slot, h_t rows from
+// the h image).  Fragment-shaped global accesses (16 rows x 16 B per instruction, every wave re-reading the rows) cost
+// 27 % of the step.
+// GRP = 2: waves w and w + 4 own the SAME unit tiles for two different sample groups and share a SIMD and the W_ih /
+// bias image.  The groups are independent recurrences with their own per-step rendezvous (a monotonic LDS counter,
+// not s_barrier) and the second starts half a step late, so that one's cell update and waits sit under the other's
+// MFMAs instead of both wanting the matrix pipe, then the vector ALU, at the same moments.
 // ---------------------------------------------------------------------------
-template <int D, int S, int GRP>
+template <int D, int GRP>
 __global__ __launch_bounds__(256 * GRP, GRP) void k_lstm_mfma(float* __restrict__ x, const float* __restrict__ wih,
-                                                      const float* __restrict__ whh, const float* __restrict__ bsum,
-                                                      int B, int L) {
+                                                              const float* __restrict__ whh,
+                                                              const float* __restrict__ bsum, int B, int L) {
   constexpr int NT = D / 4;          // unit tiles of 4 units x 4 gates == k-steps of 4
   constexpr int NTW = (NT + 3) / 4;  // tiles per wave (upper bound)
   constexpr int NG = (NT + 3) / 4;   // groups of 4 k-steps (one float4 of A fragments each)
   constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
-  // W_hh fragments stay in VGPRs (they sit on the serial h chain); the W_ih fragments and the biases are streamed from
-  // a wave-private LDS image, one ds_read_b128 per 4 k-steps -- with both matrices in registers (2 x 90 at d = 72)
-  // hipcc has no room left to keep the x / h fragments of a step in flight and serialises every load with its use.
+  constexpr int NF4 = 16 * NT;       // float4 slots of a 16-row tile
+  constexpr int NSL = (NF4 + 255) / 256;  // slots per thread of a group
   extern __shared__ __align__(16) float lds[];
-  float4* wlds = reinterpret_cast<float4*>(lds);            // [wave 4][g NG][tt NTW][lane 64]
-  float4* blds = wlds + 4 * NG * NTW * 64;                  // [wave 4][tt NTW][lane 64]  (accumulator layout)
+  float4* wlds = reinterpret_cast<float4*>(lds);  // [wave 4][g NG][tt NTW][lane 64]
+  float4* blds = wlds + 4 * NG * NTW * 64;        // end of the weight image
   const int lane = threadIdx.x & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile ownership tests are s_cbranch, not exec masks
-  // GRP = 2: waves w and w + 4 own the SAME unit tiles for two different groups of 16 S samples.  They share a SIMD
-  // (a workgroup's waves are dealt to the SIMDs cyclically), so one's cell update / LDS waits run under the other's
-  // MFMAs, and they share the W_ih / bias image in LDS.
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile ownership tests are s_cbranch
   const int wave = wave8 & 3, grp = wave8 >> 2;
-  float* hbuf = reinterpret_cast<float*>(blds + 4 * NTW * 64) + grp * (2 * S * 16 * HS);  // per group: [2][S][16][HS]
+  const int tg = threadIdx.x & 255;  // thread of the group
+  float* gbase = reinterpret_cast<float*>(blds) + grp * (5 * 16 * HS);
+  float* hbuf = gbase;                // [2][16][HS]  h_{t-1} / h_t
+  float* xbuf = gbase + 2 * 16 * HS;  // [3][16][HS]  x_t rows in slot t % 3
+  unsigned* gcnt = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(blds) + GRP * (5 * 16 * HS)) + grp;
   const int j = lane & 15, q = lane >> 4;
   const int t0 = wave * (NT / 4) + min(wave, NT % 4);
   const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
-  // A wave with fewer than NTW tiles runs the MFMAs of its phantom tile on zero weights: the step is paced by the
-  // NTW-tile waves anyway (barrier), and the main loop stays straight-line code.
 
   // weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]) and biases (accumulator layout)
   float wh[NTW][NT];
+  f32x4 bias[NTW];
 #pragma unroll
   for (int tt = 0; tt < NTW; ++tt) {
     const int T = min(t0 + tt, NT - 1);
@@ -245,47 +253,72 @@ __global__ __launch_bounds__(256 * GRP, GRP) void k_lstm_mfma(float* __restrict_
         v.w = (on && 4 * g + 3 < NT) ? wih[row + 4 * (4 * g + 3) + q] : 0.f;
         wlds[((wave * NG + g) * NTW + tt) * 64 + lane] = v;
       }
-      float4 bv;
-      bv.x = on ? bsum[0 * D + 4 * T + q] : 0.f;
-      bv.y = on ? bsum[1 * D + 4 * T + q] : 0.f;
-      bv.z = on ? bsum[2 * D + 4 * T + q] : 0.f;
-      bv.w = on ? bsum[3 * D + 4 * T + q] : 0.f;
-      blds[(wave * NTW + tt) * 64 + lane] = bv;
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
   }
-  for (int i = threadIdx.x & 255; i < 2 * S * 16 * HS; i += 256) hbuf[i] = 0.f;
+  for (int i = tg; i < 2 * 16 * HS; i += 256) hbuf[i] = 0.f;
+  if (tg == 0) *gcnt = 0u;
   const float4* wl = wlds + (size_t)wave * NG * NTW * 64 + lane;
-  const float4* bl = blds + (size_t)wave * NTW * 64 + lane;
 
-  const int b0 = (blockIdx.x * GRP + grp) * (16 * S);
-  float* xrow[S];
-  bool live[S];
+  // this thread's float4 slots of the tile's rows: slot f -> row f / NT, columns 4 (f % NT) .. +3
+  const int b0 = (blockIdx.x * GRP + grp) * 16;
+  float* gp[NSL];   // global address of the slot at t = 0 (sample clamped; stores masked by `ok`)
+  int lo[NSL];      // LDS float offset of the slot inside a [16][HS] image
+  bool has[NSL], ok[NSL];
 #pragma unroll
-  for (int ss = 0; ss < S; ++ss) {
-    const int b = b0 + 16 * ss + j;
-    live[ss] = b < B;
-    xrow[ss] = x + (size_t)min(b, B - 1) * L * D + q;
+  for (int k = 0; k < NSL; ++k) {
+    const int f = tg + 256 * k;
+    has[k] = f < NF4;
+    const int r = min(f, NF4 - 1) / NT, c4 = min(f, NF4 - 1) - r * NT;
+    ok[k] = has[k] && b0 + r < B;
+    gp[k] = x + ((size_t)min(b0 + r, B - 1) * L) * D + 4 * c4;
+    lo[k] = r * HS + 4 * c4;
   }
-  float c[NTW][S];
+  auto gload = [&](int t, float4 (&dst)[NSL]) {
 #pragma unroll
-  for (int tt = 0; tt < NTW; ++tt)
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) dst[k] = *reinterpret_cast<const float4*>(gp[k] + (size_t)t * D);
+  };
+  auto xput = [&](int par, const float4 (&src)[NSL]) {  // rows -> x ring slot `par` (8-byte aligned rows)
 #pragma unroll
-    for (int ss = 0; ss < S; ++ss) c[tt][ss] = 0.f;
-
-  // One cell step.  xc holds x_t as B fragments (k-step s <-> units 4 s + q); the fragments of x_{t+1} are requested
-  // into xn right after the input-part MFMAs were issued, a full step ahead of their use.  The time loop below is
-  // unrolled by two with the roles of the two fragment sets swapped, so no register copy ties the loads to their use.
-  // xr: x_t[u] of the lane's own units (residual input); a second, 5-value view of the same rows (L1 hits) -- selecting
-  // them out of the fragment registers by the runtime tile index costs an 18-way v_cndmask chain per value
-  auto step = [&](int t, int cur, float (&xc)[S][NT], float (&xn)[S][NT], float (&xrc)[S][NTW], float (&xrn)[S][NTW]) {
-    // input part (independent of h): acc = b + W_ih x_t
-    f32x4 acc[NTW][S];
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) {
+        float2* d2 = reinterpret_cast<float2*>(xbuf + par * 16 * HS + lo[k]);
+        d2[0] = float2{src[k].x, src[k].y};
+        d2[1] = float2{src[k].z, src[k].w};
+      }
+  };
+  // x_t + h_t -> global: x_t rows from ring slot `xs` (this thread's own float4s), h_t rows from h image `par`
+  auto out_store = [&](int t, int par, int xs) {
 #pragma unroll
-    for (int tt = 0; tt < NTW; ++tt) {
-      const float4 bv = bl[tt * 64];
-#pragma unroll
-      for (int ss = 0; ss < S; ++ss) acc[tt][ss] = f32x4{bv.x, bv.y, bv.z, bv.w};
+    for (int k = 0; k < NSL; ++k)
+      if (ok[k]) {
+        const float2* h2 = reinterpret_cast<const float2*>(hbuf + par * 16 * HS + lo[k]);
+        const float2* x2 = reinterpret_cast<const float2*>(xbuf + xs * 16 * HS + lo[k]);
+        const float2 a = h2[0], b = h2[1], u = x2[0], v = x2[1];
+        *reinterpret_cast<float4*>(gp[k] + (size_t)t * D) = float4{u.x + a.x, u.y + a.y, v.x + b.x, v.y + b.y};
+      }
+  };
+  // rendezvous of the group's four waves number `n` (1-based): every wave's LDS stores issued before its arrival
+  // are visible after it (LDS executes a wave's operations in order; fences keep hipcc from moving accesses across)
+  auto rendezvous = [&](unsigned n) {
+    if (GRP == 1) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(gcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      while (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * n) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+  };
+  // acc = b + W_ih x_t for this wave's tiles, x_t fragments from x image `par`
+  auto input_part = [&](int par, f32x4 (&acc)[NTW]) {
+    float xf[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) xf[s] = xbuf[(par * 16 + j) * HS + 4 * s + q];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias[tt];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float4 wv[NTW];
@@ -298,101 +331,95 @@ __global__ __launch_bounds__(256 * GRP, GRP) void k_lstm_mfma(float* __restrict_
 #pragma unroll
           for (int tt = 0; tt < NTW; ++tt) {
             const float a = i == 0 ? wv[tt].x : i == 1 ? wv[tt].y : i == 2 ? wv[tt].z : wv[tt].w;
-#pragma unroll
-            for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(a, xc[ss][s], acc[tt][ss]);
+            acc[tt] = mfma16(a, xf[s], acc[tt]);
           }
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < L) {
+  };
+
+  float c[NTW];
 #pragma unroll
-      for (int ss = 0; ss < S; ++ss)
+  for (int tt = 0; tt < NTW; ++tt) c[tt] = 0.f;
+  // this thread's row slots in flight: xn = x_{t+2} (loaded a step ago, put into the ring this step)
+  float4 xn[NSL];
+  gload(0, xn);
+  xput(0, xn);
+  if (L > 1) {
+    gload(1, xn);
+    xput(1, xn);
+  }
+  if (L > 2) gload(2, xn);
+  __syncthreads();  // weight / bias / h / x images written (all groups)
+  if (GRP == 2 && grp == 1) __builtin_amdgcn_s_sleep(80);  // ~5k cycles: half a cell step out of phase with group 0
+  f32x4 acc[NTW];
+  input_part(0, acc);
+  int s0 = 0, s1 = 1, s2 = 2;  // ring slots of x_t, x_{t+1}, x_{t+2} (= the slot x_{t-1} occupied)
+  for (int t = 0; t < L; ++t) {
+    const int cur = t & 1;
+    rendezvous((unsigned)t + 1);  // h_{t-1} (h image cur) and x_{t+1} (ring slot s1) are complete
+    if (t > 0) out_store(t - 1, cur, s2);  // x_{t-1} + h_{t-1}
+    float hb[NT];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) xn[ss][s] = xrow[ss][(size_t)(t + 1) * D + 4 * s];
-#pragma unroll
-      for (int ss = 0; ss < S; ++ss)
-#pragma unroll
-        for (int tt = 0; tt < NTW; ++tt) xrn[ss][tt] = xrow[ss][(size_t)(t + 1) * D + 4 * min(t0 + tt, NT - 1)];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();  // h_{t-1} of every wave is in hbuf[cur]
-    float hb[S][NT];
-#pragma unroll
-    for (int ss = 0; ss < S; ++ss)
-#pragma unroll
-      for (int s = 0; s < NT; ++s) hb[ss][s] = hbuf[((cur * S + ss) * 16 + j) * HS + 4 * s + q];
+    for (int s = 0; s < NT; ++s) hb[s] = hbuf[(cur * 16 + j) * HS + 4 * s + q];
 #pragma unroll
     for (int s = 0; s < NT; ++s)
 #pragma unroll
-      for (int tt = 0; tt < NTW; ++tt)
-#pragma unroll
-        for (int ss = 0; ss < S; ++ss) acc[tt][ss] = mfma16(wh[tt][s], hb[ss][s], acc[tt][ss]);
+      for (int tt = 0; tt < NTW; ++tt) acc[tt] = mfma16(wh[tt][s], hb[s], acc[tt]);
     // cell update, lane-local: (i, f, g, o) = acc[0..3] of unit 4 T + q, sample j
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
       if (tt < ntw) {
-        const int u = 4 * (t0 + tt) + q;
-#pragma unroll
-        for (int ss = 0; ss < S; ++ss) {
-          const f32x4 a = acc[tt][ss];
-          const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go = sigmoid_fast(a[3]);
-          c[tt][ss] = gf * c[tt][ss] + gi * gg;
-          const float h = go * tanh_fast(c[tt][ss]);
-          hbuf[(((cur ^ 1) * S + ss) * 16 + j) * HS + u] = h;
-          if (live[ss]) xrow[ss][(size_t)t * D + 4 * (t0 + tt)] = xrc[ss][tt] + h;  // x <- x + LSTM(x)
-        }
+        const f32x4 a = acc[tt];
+        const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go = sigmoid_fast(a[3]);
+        c[tt] = gf * c[tt] + gi * gg;
+        hbuf[((cur ^ 1) * 16 + j) * HS + 4 * (t0 + tt) + q] = go * tanh_fast(c[tt]);
       }
-  };
-
-  float xa[S][NT], xb[S][NT], xra[S][NTW], xrb[S][NTW];
-#pragma unroll
-  for (int ss = 0; ss < S; ++ss) {
-#pragma unroll
-    for (int s = 0; s < NT; ++s) xa[ss][s] = xrow[ss][4 * s];
-#pragma unroll
-    for (int tt = 0; tt < NTW; ++tt) xra[ss][tt] = xrow[ss][4 * min(t0 + tt, NT - 1)];
+    if (t + 1 < L) input_part(s1, acc);  // next step's input part: x_{t+1} fragments
+    // slot s2 held x_{t-1}: every wave read its fragments two steps ago and this thread just wrote its rows back
+    if (t + 2 < L) xput(s2, xn);
+    if (t + 3 < L) gload(t + 3, xn);
+    const int r = s0;
+    s0 = s1, s1 = s2, s2 = r;
   }
-  __syncthreads();  // LDS images written
-  for (int t = 0; t < L; t += 2) {
-    step(t, 0, xa, xb, xra, xrb);
-    if (t + 1 < L) step(t + 1, 1, xb, xa, xrb, xra);
-  }
+  rendezvous((unsigned)L + 1);
+  out_store(L - 1, L & 1, s2);  // after the last rotation s2 is the slot of x_{L-1}; h_{L-1} sits in h image L & 1
 }
 
-constexpr size_t lstm_mfma_lds(int D, int S, int GRP) {
+constexpr size_t lstm_mfma_lds(int D, int GRP) {
   const int NT = D / 4, NTW = (NT + 3) / 4, NG = (NT + 3) / 4;
-  return (size_t)(4 * NG * NTW * 64 + 4 * NTW * 64) * 16 + (size_t)GRP * 2 * S * 16 * (D + 2) * 4;
+  return (size_t)(4 * NG * NTW * 64) * 16 + (size_t)GRP * 5 * 16 * (D + 2) * 4 + 16;
 }
 
 // batch from which the batch-tiled kernel is faster than one sample per workgroup (measured crossover)
-int g_lstm_mfma_min_batch = 1536;
-int g_lstm_mfma_s = 0;  // 16-sample tiles per workgroup: 0 = by batch, 1, 2
+int g_lstm_mfma_min_batch = 1792;
+int g_lstm_mfma_s = 0;  // 16-sample groups per workgroup: 0 = by batch, 1, 2
 
 bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
 
-template <int D, int S, int GRP>
+template <int D, int GRP>
 static hipError_t launch_lstm_mfma_t(float* x, const float* wih, const float* whh, const float* bsum, int B, int L,
                                      hipStream_t s) {
-  constexpr size_t lds = lstm_mfma_lds(D, S, GRP);
+  constexpr size_t lds = lstm_mfma_lds(D, GRP);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_mfma<D, S, GRP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_mfma<D, GRP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((k_lstm_mfma<D, S, GRP>), dim3(cdiv(B, 16 * S * GRP)), dim3(256 * GRP), lds, s, x, wih, whh, bsum, B, L);
+  hipLaunchKernelGGL((k_lstm_mfma<D, GRP>), dim3(cdiv(B, 16 * GRP)), dim3(256 * GRP), lds, s, x, wih, whh, bsum, B, L);
   return hipGetLastError();
 }
 
 hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
                             hipStream_t s) {
   if (B <= 0) return hipSuccess;
-  // 16 samples per workgroup (4 waves) while the 16-sample tiles do not exceed the CU count; beyond that 32 samples
-  // per workgroup as two 4-wave groups (ffd_tune "lstm_mfma_s": 1 = 16, 2 = 2 x 16 in eight waves)
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return hipErrorInvalidValue;
+  // 16 samples per workgroup (4 waves) while the 16-sample tiles do not exceed the CU count; beyond that two
+  // independent 4-wave groups per workgroup (ffd_tune "lstm_mfma_s": 1 / 2 forces either)
   const bool two = g_lstm_mfma_s ? g_lstm_mfma_s == 2 : B > 16 * 256;
   switch (D) {
 #define X(d) \
-  case d: return two ? launch_lstm_mfma_t<d, 1, 2>(x, wih, whh, bsum, B, L, s) : launch_lstm_mfma_t<d, 1, 1>(x, wih, whh, bsum, B, L, s);
+  case d: return two ? launch_lstm_mfma_t<d, 2>(x, wih, whh, bsum, B, L, s) : launch_lstm_mfma_t<d, 1>(x, wih, whh, bsum, B, L, s);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;

@@ -333,11 +333,15 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
  * Synchronous (benchmark helper only). */
 int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream);
 
-/* Diagnostic: the shader clock the chip holds under the dominant kernel.  Launches the fused FFN back to back for
- * `warm_seconds` on random data, then once more with in-kernel stamps (s_memtime / s_memrealtime around the main loop
- * of every workgroup, written to a scratch buffer nothing else reads); *ghz_out = median over workgroups of
- * shader cycles per 10 ns tick x 0.1, *loop_us_out (may be NULL) = median main-loop duration.  Synchronous. */
-int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out, void* stream);
+/* Diagnostic: the shader clock the chip holds under the dominant kernel, and a timeline of one launch.  Launches the
+ * fused FFN back to back for `warm_seconds` on random data, then once more with in-kernel stamps (s_memtime /
+ * s_memrealtime, written to a scratch buffer nothing else reads); *ghz_out = median over workgroups of shader cycles
+ * per 10 ns tick x 0.1 inside the main loop, *loop_us_out (may be NULL) = median time a workgroup spent in its main
+ * loops.  raw_out (may be NULL): up to raw_capacity records of 8 x u64 per workgroup -- [0] main-loop shader cycles,
+ * [1] main-loop 10 ns ticks, then chip-wide 100 MHz timestamps [2] entry, [3] / [4] first main loop begin / end,
+ * [5] first epilogue end, [6] exit, and [7] tiles processed; *nwg_out = workgroups that ran.  Synchronous. */
+int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out,
+                        unsigned long long* raw_out, int raw_capacity, int* nwg_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1040,7 +1040,7 @@ def test_fused_unembed_sde_tail_equals_two_kernels(ffd, name):
 
 @pytest.fixture
 def lstm_mfma(ffd):
-    """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 1536 in production) on small batches."""
+    """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 1792 in production) on small batches."""
     from fastfourierdiffusion_amd import _native as N
 
     lib = N.lib()
@@ -1049,7 +1049,7 @@ def lstm_mfma(ffd):
         assert lib.ffd_tune(b"lstm_mfma_min_batch", 1) == 0 and lib.ffd_tune(b"lstm_mfma_s", s) == 0
 
     yield force
-    assert lib.ffd_tune(b"lstm_mfma_min_batch", 1536) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
+    assert lib.ffd_tune(b"lstm_mfma_min_batch", 1792) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
 
 
 @pytest.mark.parametrize("s_tiles", [1, 2])
@@ -1081,7 +1081,7 @@ def test_lstm_mfma_ragged_batch_and_independence(ffd, lstm_mfma, s_tiles):
     sd = make_sd(c)
     B = 37
     x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444)))
-    base = m(batch_of(x.cuda(), 0.45)).cpu()  # k_lstm_layer (B < 1536)
+    base = m(batch_of(x.cuda(), 0.45)).cpu()  # k_lstm_layer (B < 1792)
     noise = list(synthetic.noise_stream((B, c["L"], c["C"]), 7, 4445))
     s0 = DiffusionSampler(m, B)
     s0.inject_noise(iter(noise))

@@ -13,7 +13,7 @@ assert ctx.lib.ffd_tune(b"ffn_mb", 4) == 0 and ctx.lib.ffd_tune(b"ffn_stagger", 
 out = []
 for B in (87, 174, 512):  # 16 269 rows = 255 tiles; 32 538 rows = 509 tiles; the bench shape
     ghz, us = C.c_double(), C.c_double()
-    N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, 1.0, C.byref(ghz), C.byref(us), s), ctx.handle, "probe")
+    N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, 1.0, C.byref(ghz), C.byref(us), None, 0, None, s), ctx.handle, "probe")
     ms = C.c_float()
     N.check(ctx.lib.ffd_bench_ffn(ctx.handle, B, 50, C.byref(ms), s), ctx.handle, "bench")
     tiles = (B * 187 + 63) // 64

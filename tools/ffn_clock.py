@@ -14,7 +14,7 @@ s = N.current_stream_ptr(dev)
 out = []
 for w in (0.0, warm, warm):
     ghz, us = C.c_double(), C.c_double()
-    N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, w, C.byref(ghz), C.byref(us), s), ctx.handle, "probe")
+    N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, w, C.byref(ghz), C.byref(us), None, 0, None, s), ctx.handle, "probe")
     ms = C.c_float()
     N.check(ctx.lib.ffd_bench_ffn(ctx.handle, B, 50, C.byref(ms), s), ctx.handle, "bench")
     out.append({"warm_s": w, "shader_clock_ghz": ghz.value, "main_loop_us_median": us.value, "kernel_us_back_to_back": ms.value * 1e3})

@@ -1,0 +1,31 @@
+"""Timeline of ONE launch of the fused FFN at the bench shape from in-kernel 100 MHz timestamps (ffd_probe_ffn_clock):
+when workgroups enter, how long prologue / main loop / epilogue of their first tile take, when they exit.
+tools/ffn_timeline.py [B] [persist]"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from fastfourierdiffusion_amd import _native as N
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+persist = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dev = torch.device("cuda", 0)
+model, sch, _ = bench.build_model(dev, "ecg")
+ctx = model._ctx()
+s = N.current_stream_ptr(dev)
+assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0
+cap = 4096
+raw = (C.c_uint64 * (8 * cap))()
+ghz, us, n = C.c_double(), C.c_double(), C.c_int()
+N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, 1.0, C.byref(ghz), C.byref(us), raw, cap, C.byref(n), s), ctx.handle, "probe")
+r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value].astype(np.float64)
+t0 = r[:, 2].min()
+q = lambda a: [round(float(v), 2) for v in np.percentile(a, [0, 10, 50, 90, 100])]
+tk = 0.01  # us per tick
+out = {"B": B, "persist": persist, "workgroups": int(n.value), "shader_clock_ghz": ghz.value,
+       "tiles_per_workgroup": q(r[:, 7]),
+       "entry_us": q((r[:, 2] - t0) * tk), "exit_us": q((r[:, 6] - t0) * tk),
+       "first_prologue_us": q((r[:, 3] - r[:, 2]) * tk), "first_main_loop_us": q((r[:, 4] - r[:, 3]) * tk),
+       "first_epilogue_us": q((r[:, 5] - r[:, 4]) * tk), "main_loops_total_us": q(r[:, 1] * tk),
+       "lifetime_us": q((r[:, 6] - r[:, 2]) * tk), "percentiles": [0, 10, 50, 90, 100]}
+print(json.dumps(out))
