@@ -421,9 +421,12 @@ def main() -> None:
             from fastfourierdiffusion_amd.benchmark import benchmark_sampling, run_cache_benchmark
 
             ns, nd = 10, 100
-            r_off = benchmark_sampling(model, ns, nd, use_cache=False)
-            r_on = benchmark_sampling(model, ns, nd, use_cache=True, cache_kwargs={})
-            model.disable_caching()
+            # a fresh model, as in the reference's script: the harness's enable_caching is then the model's FIRST, the
+            # one whose cache object the layers report to (later ones read zero hits)
+            hmodel, _, _ = build_model(device, "ecg")
+            r_off = benchmark_sampling(hmodel, ns, nd, use_cache=False)
+            r_on = benchmark_sampling(hmodel, ns, nd, use_cache=True, cache_kwargs={})
+            hmodel.disable_caching()
             hb = {"sample_batch_size": 1, "num_samples": ns, "num_diffusion_steps": nd,
                   "ms_per_step_off": r_off["elapsed_time"] / (ns * nd) * 1e3,
                   "ms_per_step_on": r_on["elapsed_time"] / (ns * nd) * 1e3,
@@ -437,8 +440,9 @@ def main() -> None:
                 hb["ratio_vs_cpu_ratio"] = hb["off_over_on"] / hb["cpu_oracle"]["off_over_on"]
             out["harness_b1"] = hb
             if args.ablation:
-                rows = run_cache_benchmark(model, num_samples=ns, num_diffusion_steps=nd)
-                model.disable_caching()
+                gmodel, _, _ = build_model(device, "ecg")
+                rows = run_cache_benchmark(gmodel, num_samples=ns, num_diffusion_steps=nd)
+                gmodel.disable_caching()
                 out["ablation"] = [{k: v for k, v in r.items()} for r in rows]
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (a bounded ~25 s CPU sample)
             out["cpu_baseline"] = cpu_baseline(sd, L, Cn, model.num_layers, model.n_head,

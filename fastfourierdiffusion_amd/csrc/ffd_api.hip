@@ -77,6 +77,7 @@ struct ffd_ctx {
   float tm_ms[FFD_K_COUNT] = {0};
   int tm_n[FFD_K_COUNT] = {0};
   float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
+  int* ffn_ctr = nullptr;   // dynamic tile counters of the persistent FFN (zero between launches)
   // FreSca (sampler-level)
   bool fresca_on = false;
   bool crf_cap_on = false;
@@ -177,6 +178,14 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "ffn_persist")) {  // 0: one workgroup per tile; n >= 1: persistent grid of n x the resident workgroups
     if (value < 0 || value > 8) return FFD_ERR_INVALID;
     g_ffn_persist = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_prio")) {  // raised wave priority outside the FFN main loop
+    g_ffn_prio = value ? 1 : 0;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_dynamic")) {  // persistent FFN: tiles from a device counter (1) or static round robin (0)
+    g_ffn_dynamic = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_rem")) {
@@ -307,6 +316,10 @@ int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
   HIPCHECK(hipMemcpy(ctx->G_dev, ctx->G_host.data(), sizeof(float) * m.max_len, hipMemcpyHostToDevice));
   rc = dev_alloc(ctx, &ctx->temb1, m.d_model);
   if (rc) return rc;
+  float* ctr = nullptr;
+  if ((rc = dev_alloc(ctx, &ctr, 64))) return rc;
+  HIPCHECK(hipMemset(ctr, 0, 64 * sizeof(float)));
+  ctx->ffn_ctr = reinterpret_cast<int*>(ctr);
   return FFD_OK;
 }
 
@@ -627,7 +640,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
         HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
     }
     TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-    TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s));
+    TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
       // straight into this layer's tables: head-major (1,H,L,hd) == table layout
@@ -1215,7 +1228,9 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);
   HIPCHECK(hipGetLastError());
-  auto run = [&]() -> hipError_t { return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s); };
+  auto run = [&]() -> hipError_t {
+    return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, nullptr, ctx->ffn_ctr);
+  };
   for (int i = 0; i < 3; ++i) HIPCHECK(run());
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
@@ -1257,14 +1272,15 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   HIPCHECK(hipEventRecord(e0, s));
   double elapsed = 0.0;
   while (elapsed < warm_seconds) {
-    for (int i = 0; i < 50; ++i) HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s));
+    for (int i = 0; i < 50; ++i)
+      HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, nullptr, ctx->ffn_ctr));
     HIPCHECK(hipEventRecord(e1, s));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
     elapsed = ms * 1e-3;
   }
-  HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, stamps));
+  HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, stamps, ctx->ffn_ctr));
   std::vector<unsigned long long> h(8 * (size_t)nwg);
   HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
                                                   const float* __restrict__ W2r, const float* __restrict__ b2,
                                                   const float* __restrict__ gam, const float* __restrict__ bet,
                                                   float* __restrict__ Y, int M, int F, int stagger,
-                                                  unsigned long long* __restrict__ stamp) {
+                                                  unsigned long long* __restrict__ stamp, int* __restrict__ tile_ctr) {
+  // tile_ctr (persistent form; nullptr = static round robin): [0] next unassigned tile - gridDim.x, [1] workgroups
+  // that have exited.  Tiles are handed out dynamically: in-kernel timestamps showed 10-20 % of the workgroups of a
+  // statically partitioned launch finishing 60-70 us after the median (the launch then waits for them with most CUs
+  // idle).  The tile -> workgroup map never shows in the result (fixed reduction order inside a tile).
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): shader-clock and 100 MHz real-time
   // deltas around the main loops, written to memory nothing else reads (MI355X_MICROARCH.md, DVFS item 6)
   constexpr int S = lds_stride(D);
@@ -66,12 +70,15 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   constexpr int NRED = DMA ? 2 : 3;  // partial-sum buffers (the persistent form trades one for the second X image)
   __shared__ __align__(16) float xsb[NBUF * R * SX];
   __shared__ __align__(16) float red[NRED * R * S2];
+  __shared__ int s_next;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntiles = (M + R - 1) / R;
+  const bool prio_epilogue = (stagger & 0x40000000) != 0;  // (launcher flag folded into the stagger argument)
+  stagger &= 0x3FFFFFFF;
 
   // a tile's X rows -> image `b`, asynchronously (rows past M repeat the last valid row; they are never stored)
   auto issue_dma = [&](int t, int b) {
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 
   int tile = blockIdx.x;
   int buf = 0;
+  if (DMA && tile_ctr && threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(tile_ctr, 1);  // read after the first barrier
   if (DMA) {
     issue_dma(tile, 0);
   } else {
@@ -160,8 +168,11 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * SX + 4 * s + (lane >> 4)];
-    const int tile_next = tile + (int)gridDim.x;
+    const int tile_next = (DMA && tile_ctr) ? s_next : tile + (int)gridDim.x;
     if (DMA && tile_next < ntiles) issue_dma(tile_next, buf ^ 1);
+    // request the tile after next now; the answer is parked in s_next after the reduction barrier below
+    int tile_req = 0;
+    if (DMA && tile_ctr && threadIdx.x == 0 && tile_next < ntiles) tile_req = atomicAdd(tile_ctr, 1);
 
     f32x4 yacc[CT][MB];
 #pragma unroll
@@ -174,6 +185,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (prio_epilogue) __builtin_amdgcn_s_setprio(0);
     if (stamp) {  // scalar: stays in SGPRs
       st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
       if (st_tiles == 0) st_first_b = st_rt;
@@ -232,6 +244,10 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
       if (st_tiles == 0) st_first_e = rt;
     }
 
+    // Outside the main loop this wave competes with the other resident workgroup's MFMA stream for issue slots and
+    // was measured starving (epilogue 4-5 us alone, 26 us beside a main loop): raise its priority until it is back in
+    // its own main loop, so the pair spends more of the time in the 98 %-busy both-in-main-loop regime.
+    if (prio_epilogue) __builtin_amdgcn_s_setprio(3);
     // ---- deterministic cross-wave reduction through LDS, fixed order of additions:
     //   3 buffers (small M): wave 0 adds its partial into the X tile (= the residual), waves 1..3 park theirs;
     //                        row sum = ((((x + p0) + p1) + p2) + p3) + b2
@@ -252,6 +268,12 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
             yrem[g][mb][i] = v;
           }
     }
+    // The epilogue's index arithmetic is recomputed per tile from an opaque copy of the thread index: hoisted out of
+    // the tile loop as loop invariants it lived in VGPRs across the main loop, which sits at the register limit, and
+    // was spilled (24 dwords per lane: 12 MB of scratch writes per launch at the ECG shape).
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63;
     // acc = true: add to what the buffer holds (row stride st), else overwrite
     auto put_partial = [&](float* dst, int st, bool acc) {
 #pragma unroll
@@ -260,14 +282,14 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + 4 * (lane >> 4) + r;
+            const int c = 16 * ct + 4 * (lane_e >> 4) + r;
             if (c < D) {
-              float* q = &dst[(16 * mb + (lane & 15)) * st + c];
+              float* q = &dst[(16 * mb + (lane_e & 15)) * st + c];
               *q = acc ? *q + yacc[ct][mb][r] : yacc[ct][mb][r];
             }
           }
-      if (NG > 0 && (lane >> 4) < NGA) {  // quarter q handles remainder group g = q
-        const int g = lane >> 4;
+      if (NG > 0 && (lane_e >> 4) < NGA) {  // quarter q handles remainder group g = q
+        const int g = lane_e >> 4;
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
             float v = 0.f;
 #pragma unroll
             for (int gg = 0; gg < NGA; ++gg) v = (gg == g) ? yrem[gg][mb][i] : v;
-            float* q = &dst[(16 * mb + (lane & 15)) * st + 16 * CT + 4 * g + i];
+            float* q = &dst[(16 * mb + (lane_e & 15)) * st + 16 * CT + 4 * g + i];
             *q = acc ? *q + v : v;
           }
       }
@@ -283,6 +305,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     if (wave == 0) put_partial(xs, SX, true);
     else if (wave <= NRED) put_partial(red + (size_t)(wave - 1) * R * S2, S2, false);
     __syncthreads();
+    if (DMA && tile_ctr && threadIdx.x == 0) s_next = (int)gridDim.x + tile_req;  // every thread has read s_next by now
     if (NRED == 2) {
       if (wave == 3) put_partial(red, S2, true);
       __syncthreads();
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 
     // ---- + b2, LayerNorm2, coalesced store ----
     constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
-    const int row = threadIdx.x / TPR, sub = threadIdx.x % TPR;
+    const int row = tid_e / TPR, sub = tid_e % TPR;
     const int m = m0 + row;
     float vals[cdiv(D, TPR)];
     float sum = 0.f;
@@ -339,6 +362,13 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     // (the barrier at the top of the next iteration orders this tile's LDS reads before the next reduction's
     //  writes: the images alternate, and `red` is next written after that barrier)
   }
+  if (DMA && tile_ctr && threadIdx.x == 0) {
+    // the last workgroup out re-arms the counters for the next launch (all others are past their last access)
+    if (atomicAdd(tile_ctr + 1, 1) == (int)gridDim.x - 1) {
+      tile_ctr[0] = 0;
+      tile_ctr[1] = 0;
+    }
+  }
   if (stamp && threadIdx.x == 0) {
     unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
     o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
@@ -346,6 +376,8 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   }
 }
 
+int g_ffn_prio = 0;         // 1: waves outside their main loop run at raised priority (ffd_tune "ffn_prio")
+int g_ffn_dynamic = 0;      // 1: the persistent grid takes tiles from a device counter; 0: static round robin
 int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
 static int num_cus() {
   static int n = 0;
@@ -363,7 +395,7 @@ int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ff
 
 template <int D>
 static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
-                               unsigned long long* stamp) {
+                               unsigned long long* stamp, int* tile_ctr) {
   // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
   // and is the default once the grid fills the chip; smaller tiles for small batches.
   int mb = g_ffn_mb_override;
@@ -374,7 +406,8 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   // With two resident workgroups per CU and at least two rounds of tiles, de-phase the pair by about one
   // prologue + epilogue so that one workgroup's non-MFMA phases run under the other's main loop
   // (measured 469 -> 457 us on the 95744 x 72 x 2048 shape, tools/sweep_stagger.py).
-  const int stagger = g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0;
+  const int stagger = (g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0) |
+                      (g_ffn_prio ? 0x40000000 : 0);
   dim3 block(256);
   // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
   const int resident = num_cus() * (mb == 4 ? 2 : 1) * (g_ffn_persist > 0 ? g_ffn_persist : 1);
@@ -382,14 +415,15 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     const int ntiles = cdiv(M, 16 * mbv);
     return dim3((mbv >= 4 && g_ffn_persist != 0 && ntiles > resident) ? resident : ntiles);
   };
+  if (g_ffn_dynamic == 0) tile_ctr = nullptr;
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
     if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,             \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp, tile_ctr);                                      \
     else                                                                                                          \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,            \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp, tile_ctr);                                      \
   } while (0)
   switch (mb) {
     case 8: FFD_LAUNCH_FFN(8); break;
@@ -408,12 +442,12 @@ int ffn_tile_rows(int M) {  // rows per workgroup launch_ffn_ln picks (one stamp
 }
 
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
-                         unsigned long long* stamp) {
+                         unsigned long long* stamp, int* tile_ctr) {
   if (M <= 0) return hipSuccess;
   if (F % 64 != 0) return hipErrorInvalidValue;
   switch (D) {
 #define X(d) \
-    case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp);
+    case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp, tile_ctr);
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -104,13 +104,17 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
                                 const float* beta, float* Y, int M, int D, hipStream_t s);
 // Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
 // stamp != nullptr (diagnostics): per-workgroup (shader-clock, 100 MHz real-time) deltas around the main loop
+// tile_ctr: two zero-initialised device ints owned by the context (dynamic tile hand-out of the persistent form; the
+// kernel re-arms them); nullptr = static partition
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
-                         unsigned long long* stamp = nullptr);
+                         unsigned long long* stamp = nullptr, int* tile_ctr = nullptr);
 int ffn_tile_rows(int M);
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
 extern int g_ffn_stagger;
 extern int g_ffn_persist;
+extern int g_ffn_dynamic;
+extern int g_ffn_prio;
 extern int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
 size_t attn_pack_floats(int D, int H, int hpw, int q_only);

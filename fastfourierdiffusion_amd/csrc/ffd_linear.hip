@@ -176,90 +176,144 @@ __global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, 
   }
 }
 
+// out-proj + residual + LayerNorm1.  HBM-bound: 12 d bytes per row (attention output and residual in, LN1 output
+// out) against 2 d^2 FLOP.  Persistent over 64-row tiles (grid = the workgroups the chip holds, two per CU): the
+// weight fragments stay in registers for all tiles, the NEXT tile's X and R rows stream into the second half of a
+// double-buffered LDS image by LDS-DMA (global_load_lds_dwordx4, no VGPRs) while the current tile is computed, and the
+// finished rows leave through the wave's own rows of the X image as whole 1 KiB runs (the accumulator layout would
+// store sixteen 64-byte pieces per instruction).  One workgroup per tile took 28 us on the ECG shape: two dependent
+// HBM round trips per workgroup and 1.46 rounds of workgroups.
 template <int D>
-__global__ __launch_bounds__(256) void k_linear_res_ln(const float* __restrict__ X, const float* __restrict__ Wp,
-                                                       const float* __restrict__ bias, const float* __restrict__ R,
-                                                       const float* __restrict__ gam, const float* __restrict__ bet,
-                                                       float* __restrict__ Y, int M) {
-  constexpr int S = lds_stride(D);
+__global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                          const float* __restrict__ bias, const float* __restrict__ R,
+                                                          const float* __restrict__ gam, const float* __restrict__ bet,
+                                                          float* __restrict__ Y, int M) {
   constexpr int KS = D / 4;
   constexpr int G = dpack_groups(D);
   constexpr int CT = cdiv(D, 16);
-  __shared__ __align__(16) float xs[64 * S];
-  __shared__ __align__(16) float rs[64 * S];
-  const int m0 = blockIdx.x * 64;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // every weight fragment up front (CT*G float4 per lane): latency hides under the tile staging
+  constexpr int SX = ((D + 3) / 4) * 4 + 4;  // image row stride: whole float4 slots (lane-linear LDS-DMA image), one pad slot
+  constexpr int S4 = SX / 4;
+  constexpr int TR = 64;                     // rows per tile
+  constexpr int NPC = (TR * S4 + 63) / 64;   // 1 KiB DMA pieces per image
+  __shared__ __align__(16) float img[2][2][TR * SX];  // [buffer][X | R][row][SX]
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ntiles = (M + TR - 1) / TR;
+  // every weight fragment up front (CT*G float4 per lane), resident for all tiles
   const float4* Wq = reinterpret_cast<const float4*>(Wp);
   float4 wq[CT][G];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int g = 0; g < G; ++g) wq[ct][g] = Wq[((size_t)ct * G + g) * 64 + lane];
-  __builtin_amdgcn_sched_barrier(0);
-  load_x_tile<D>(X, xs, m0, M);
-  load_x_tile<D>(R, rs, m0, M);
-  __syncthreads();
-  float xf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) xf[s] = xs[(16 * wave + (lane & 15)) * S + 4 * s + (lane >> 4)];
 
-  f32x4 acc[CT];
+  // bias / LN scale / shift of this lane's columns too: an ordinary global load inside the tile loop would make hipcc
+  // drain the in-flight LDS-DMA (vmcnt(0)) at its first use
+  float4 bq[CT], gq[CT], eq[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
-    acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 q = wq[ct][s >> 2];
-      const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
-      acc[ct] = mfma16(a, xf[s], acc[ct]);
-    }
+    const int n = 16 * ct + 4 * (lane >> 4);
+    const bool in = n < D;
+    bq[ct] = in ? *reinterpret_cast<const float4*>(bias + n) : float4{0.f, 0.f, 0.f, 0.f};
+    gq[ct] = in ? *reinterpret_cast<const float4*>(gam + n) : float4{0.f, 0.f, 0.f, 0.f};
+    eq[ct] = in ? *reinterpret_cast<const float4*>(bet + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
-  // epilogue: lane holds row m, columns n = 16 ct + 4 (lane>>4) + r
-  const int m = m0 + 16 * wave + (lane & 15);
-  const float* rrow = &rs[(16 * wave + (lane & 15)) * S];
-  float v[CT][4];
-  float sum = 0.f;
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = 16 * ct + 4 * (lane >> 4) + r;
-      if (n < D) {
-        v[ct][r] = acc[ct][r] + bias[n] + rrow[n];
-        sum += v[ct][r];
-      } else {
-        v[ct][r] = 0.f;
+  auto issue_dma = [&](int t, int b) {  // rows past M repeat the last valid row (never stored)
+    const int rows_valid = min(TR, M - t * TR);
+    const size_t base = (size_t)t * TR * D;
+    for (int pc = wave; pc < NPC; pc += 4) {
+      const int p = pc * 64 + lane;
+      const int r = p / S4, c4 = p - r * S4;
+      const size_t off = base + (size_t)min(r, rows_valid - 1) * D + 4 * min(c4, D / 4 - 1);
+      if (p < TR * S4) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(X + off), (lds_ptr_t)(&img[b][0][pc * 256]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(R + off), (lds_ptr_t)(&img[b][1][pc * 256]), 16, 0, 0);
       }
     }
-  sum += __shfl_xor(sum, 16);
-  sum += __shfl_xor(sum, 32);
-  const float mean = sum * (1.0f / D);
-  float ss = 0.f;
+  };
+
+  int buf = 0;
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_dma(tile, 0);
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's images have landed (and the previous tile's stores left)
+    __syncthreads();
+    float* xs = img[buf][0];
+    const float* rs = img[buf][1];
+    float xf[KS];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
+    for (int s = 0; s < KS; ++s) xf[s] = xs[(16 * wave + (lane & 15)) * SX + 4 * s + (lane >> 4)];
+    if (tile + (int)gridDim.x < ntiles) issue_dma(tile + gridDim.x, buf ^ 1);
+
+    f32x4 acc[CT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = 16 * ct + 4 * (lane >> 4) + r;
-      if (n < D) {
-        float dlt = v[ct][r] - mean;
-        ss = fmaf(dlt, dlt, ss);
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {  // k outer: CT independent accumulation chains
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float4 q = wq[ct][s >> 2];
+        const float a = (s & 3) == 0 ? q.x : (s & 3) == 1 ? q.y : (s & 3) == 2 ? q.z : q.w;
+        acc[ct] = mfma16(a, xf[s], acc[ct]);
       }
     }
-  ss += __shfl_xor(ss, 16);
-  ss += __shfl_xor(ss, 32);
-  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
-  if (m < M) {
+    // epilogue: lane holds row (lane & 15) of the wave's 16, columns n = 16 ct + 4 (lane >> 4) + r
+    const int lr = 16 * wave + (lane & 15);
+    const float* rrow = rs + lr * SX;
+    float v[CT][4];
+    float sum = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int n = 16 * ct + 4 * (lane >> 4);
-      if (n + 3 < D) {
-        float4 g4 = *reinterpret_cast<const float4*>(gam + n);
-        float4 b4 = *reinterpret_cast<const float4*>(bet + n);
-        float4 o = {(v[ct][0] - mean) * rstd * g4.x + b4.x, (v[ct][1] - mean) * rstd * g4.y + b4.y,
-                    (v[ct][2] - mean) * rstd * g4.z + b4.z, (v[ct][3] - mean) * rstd * g4.w + b4.w};
-        *reinterpret_cast<float4*>(Y + (size_t)m * D + n) = o;
+      if (n < D) {  // D % 4 == 0: whole quads
+        const float4 r4 = *reinterpret_cast<const float4*>(rrow + n);
+        const float4 b4 = bq[ct];
+        v[ct][0] = acc[ct][0] + b4.x + r4.x, v[ct][1] = acc[ct][1] + b4.y + r4.y;
+        v[ct][2] = acc[ct][2] + b4.z + r4.z, v[ct][3] = acc[ct][3] + b4.w + r4.w;
+        sum += (v[ct][0] + v[ct][1]) + (v[ct][2] + v[ct][3]);
+      } else {
+        v[ct][0] = v[ct][1] = v[ct][2] = v[ct][3] = 0.f;
       }
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / D);
+    float ss = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = 16 * ct + 4 * (lane >> 4);
+      if (n < D) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dlt = v[ct][r] - mean;
+          ss = fmaf(dlt, dlt, ss);
+        }
+      }
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+    // finished rows -> the wave's own rows of the X image (its fragments are in registers; no other wave reads them)
+    float* orow = xs + lr * SX;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = 16 * ct + 4 * (lane >> 4);
+      if (n < D) {
+        const float4 g4 = gq[ct], b4 = eq[ct];
+        *reinterpret_cast<float4*>(orow + n) =
+            float4{(v[ct][0] - mean) * rstd * g4.x + b4.x, (v[ct][1] - mean) * rstd * g4.y + b4.y,
+                   (v[ct][2] - mean) * rstd * g4.z + b4.z, (v[ct][3] - mean) * rstd * g4.w + b4.w};
+      }
+    }
+    // ... and out as contiguous runs: the wave's 16 rows are 16 * D consecutive floats of Y
+    const int row0 = tile * TR + 16 * wave;
+    float4* y4 = reinterpret_cast<float4*>(Y + (size_t)row0 * D);
+    const int nvalid = min(16, M - row0);  // (<= 0: nothing to store)
+    for (int f = lane; f < 16 * (D / 4); f += 64) {
+      const int r = f / (D / 4), c4 = f - r * (D / 4);
+      if (r < nvalid) y4[f] = *reinterpret_cast<const float4*>(xs + (16 * wave + r) * SX + 4 * c4);
     }
   }
 }
@@ -392,7 +446,17 @@ hipError_t launch_linear_hm(const float* X, const float* Wp, const float* bias, 
 hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bias, const float* R, const float* g,
                                 const float* beta, float* Y, int M, int D, hipStream_t s) {
   if (M <= 0) return hipSuccess;
-  dim3 grid(cdiv(M, 64)), block(256);
+  if (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(R) | reinterpret_cast<uintptr_t>(Y)) & 15) != 0)
+    return hipErrorInvalidValue;
+  static int resident = 0;  // persistent grid: two workgroups per CU
+  if (resident == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    resident = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512;
+  }
+  const int ntiles = cdiv(M, 64);
+  dim3 grid(ntiles < resident ? ntiles : resident), block(256);
   switch (D) {
 #define X(d) \
     case d: hipLaunchKernelGGL(k_linear_res_ln<d>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;

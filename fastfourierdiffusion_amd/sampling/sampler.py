@@ -13,8 +13,15 @@ Noise: ``rng="torch"`` (default) draws z exactly where the reference does --
 ``torch.randn`` on the CPU generator for the prior, ``torch.randn_like`` on the device
 generator for every step -- so a seeded run matches the reference run on the same
 device.  ``rng="philox"`` generates the draws inside the step kernel (Philox4x32-10
-keyed by (seed, step, global element index)): no z traffic, and results are invariant
+keyed by (seed, step, global element index)): no z traffic, and the NOISE is invariant
 to how samples are sharded over GPUs.
+
+Two batch-wide statistics of the reference make the SAMPLES depend on the batching all the
+same, sharded or not (they are properties of the reference's algorithm, reproduced here per
+batch / per shard): the E2-CRF tables come from the batch's element 0 (caching.py:326-328), and
+FreSca's default ``energy`` cutoff is derived from ``|rfft(score)|.mean(dim=(0, 2))`` over the
+local batch (fresca.py:150-158).  Without the cache and with FreSca off or on its ``spatial``
+cutoff a sharded philox run equals the unsharded one (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 

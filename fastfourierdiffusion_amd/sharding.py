@@ -6,7 +6,10 @@ weights replicated (12.8 MB), contiguous sample ranges per rank, Philox noise ke
 *global* sample index so results do not depend on N.  There is no data-path collective;
 torch.distributed (RCCL on GPUs, gloo in CPU tests) only carries the barrier and the
 max-over-ranks of elapsed time.  With the E2-CRF cache each shard behaves as an
-independent reference run (its own step-0 table from its own element 0).
+independent reference run (its own step-0 table from its own element 0); the same
+holds for FreSca's ``energy`` cutoff, a mean over the local batch (fresca.py:150-158): both are
+per-batch statistics in the reference, so a shard reproduces the reference run with
+``sample_batch_size`` = shard size, not a slice of a larger batch.
 """
 from __future__ import annotations
 

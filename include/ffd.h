@@ -18,7 +18,9 @@
  *   - I/O buffers are caller-owned and only borrowed for the stream-ordered
  *     call; weights are copied (and re-packed) into context-owned HBM;
  *   - one context per device; a context is not thread-safe, distinct contexts
- *     are independent (no global state);
+ *     are independent: the only process-wide state is the experiment knobs of
+ *     ffd_tune (kernel choice / tiling, never results) and a per-device cache of
+ *     FFT twiddle tables;
  *   - tensors are dense row-major fp32: series X/score (B, L, C) with C
  *     innermost and L the Fourier / attention axis (score_models.py:87-90,
  *     fourier.py:12,24).
@@ -287,6 +289,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  * parity tolerance, only the kernel choice / tiling changes):
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
  *   "ffn_persist" = 1 | 0 | n                  fused FFN at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
+ *   "ffn_dynamic" = 1 | 0                      persistent FFN: tiles handed out by a device counter, or a static partition;
+ *   "ffn_prio" = 1 | 0                         fused FFN: raised wave priority outside the main loop;
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
  *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
  *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;

@@ -1,15 +1,30 @@
 #!/bin/bash
-# Run on the GPU box: refresh the round's bench lines and rocprofv3 kernel summaries under gpurun_out/final/.
+# Run on the GPU box: the round's bench lines, rocprofv3 kernel summaries and PMC traffic passes -> gpurun_out/final/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/final
 mkdir -p $O
-python3 $R/bench.py > $O/bench_ecg_B512.json 2> $O/bench_ecg_B512.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ecg -- python3 $R/bench.py --no-extras > $O/bench_ecg_B512_profiled.json 2>/dev/null
-python3 $R/bench.py --cache --no-extras > $O/bench_ecg_B512_cache.json 2>/dev/null
-python3 $R/bench.py --workload syn512 --batch 8192 --cache --steps 3 --warmup 1 --no-extras > $O/bench_syn512_B8192_cache.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_syn -- python3 $R/bench.py --workload syn512 --batch 2048 --steps 3 --warmup 1 --no-extras > $O/bench_syn512_B2048.json 2>/dev/null
-python3 $R/bench.py --workload nasa_lstm --batch 512 --steps 200 --warmup 10 --no-extras > $O/bench_nasa_lstm_B512.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lstm -- python3 $R/bench.py --workload nasa_lstm --batch 512 --steps 20 --warmup 2 --no-extras > /dev/null 2>&1
-for d in prof_ecg prof_syn prof_lstm; do cp $O/$d/*/*kernel_stats.csv $O/${d}_kernel_stats.csv; rm -rf $O/$d; done
+prof() {  # prof <name> <bench args...>: rocprofv3 --kernel-trace --stats of one bench run -> <name>_kernel_stats.csv
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 $R/bench.py --no-extras "$@" > $O/${name}_profiled.json 2>/dev/null
+  cp $O/prof_$name/*/*kernel_stats.csv $O/${name}_kernel_stats.csv && rm -rf $O/prof_$name
+}
+python3 $R/bench.py --ablation > $O/bench_ecg_B512.json 2> $O/bench_ecg_B512.err
+echo "ecg done: $(python3 -c "import json; d=json.loads(open('$O/bench_ecg_B512.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline']['frac'])")"
+prof ecg_B512
+python3 $R/bench.py --cache --no-cpu-baseline > $O/bench_ecg_B512_cache.json 2>/dev/null
+python3 $R/bench.py --workload syn512 --batch 8192 --cache --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_syn512_B8192_cache.json 2>/dev/null
+python3 $R/bench.py --workload syn512 --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_syn512_B2048.json 2>/dev/null
+prof syn512_B2048 --workload syn512 --batch 2048 --steps 3 --warmup 1
+echo "syn512 done"
+python3 $R/bench.py --workload nasa_lstm --batch 512 --steps 200 --warmup 10 > $O/bench_nasa_lstm_B512.json 2>/dev/null
+python3 $R/bench.py --workload nasa_lstm --batch 8192 --steps 20 --warmup 2 --no-cpu-baseline > $O/bench_nasa_lstm_B8192.json 2>/dev/null
+prof nasa_lstm_B512 --workload nasa_lstm --batch 512 --steps 20 --warmup 2
+prof nasa_lstm_B8192 --workload nasa_lstm --batch 8192 --steps 5 --warmup 1
+echo "lstm done"
+bash $R/tools/collect_traffic.sh ecg:512 --steps 20 --warmup 2 > $O/traffic_ecg.log 2>&1
+bash $R/tools/collect_traffic.sh syn512:2048 --workload syn512 --batch 2048 --steps 2 --warmup 1 > $O/traffic_syn.log 2>&1
+bash $R/tools/collect_traffic.sh nasa_lstm:8192 --workload nasa_lstm --batch 8192 --steps 2 --warmup 1 > $O/traffic_lstm8192.log 2>&1
+bash $R/tools/collect_traffic.sh nasa_lstm:512 --workload nasa_lstm --batch 512 --steps 5 --warmup 1 > $O/traffic_lstm512.log 2>&1
+cp $R/gpurun_out/traffic/r02_traffic.json $O/r02_traffic.json
 ls -la $O

@@ -9,11 +9,12 @@ import bench
 from fastfourierdiffusion_amd import _native as N
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 persist = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dynamic = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda", 0)
 model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx()
 s = N.current_stream_ptr(dev)
-assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0
+assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0 and ctx.lib.ffd_tune(b"ffn_dynamic", dynamic) == 0
 cap = 4096
 raw = (C.c_uint64 * (8 * cap))()
 ghz, us, n = C.c_double(), C.c_double(), C.c_int()
@@ -22,7 +23,7 @@ r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value].astype(np.flo
 t0 = r[:, 2].min()
 q = lambda a: [round(float(v), 2) for v in np.percentile(a, [0, 10, 50, 90, 100])]
 tk = 0.01  # us per tick
-out = {"B": B, "persist": persist, "workgroups": int(n.value), "shader_clock_ghz": ghz.value,
+out = {"B": B, "persist": persist, "dynamic": dynamic, "workgroups": int(n.value), "shader_clock_ghz": ghz.value,
        "tiles_per_workgroup": q(r[:, 7]),
        "entry_us": q((r[:, 2] - t0) * tk), "exit_us": q((r[:, 6] - t0) * tk),
        "first_prologue_us": q((r[:, 3] - r[:, 2]) * tk), "first_main_loop_us": q((r[:, 4] - r[:, 3]) * tk),
