@@ -78,6 +78,8 @@ struct ffd_ctx {
   int tm_n[FFD_K_COUNT] = {0};
   float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
   int* ffn_ctr = nullptr;   // dynamic tile counters of the persistent FFN (zero between launches)
+  float* ffn_part = nullptr;  // partial Y tiles of the small-M split FFN
+  size_t ffn_part_floats = 0;
   // FreSca (sampler-level)
   bool fresca_on = false;
   bool crf_cap_on = false;
@@ -178,6 +180,20 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "ffn_persist")) {  // 0: one workgroup per tile; n >= 1: persistent grid of n x the resident workgroups
     if (value < 0 || value > 8) return FFD_ERR_INVALID;
     g_ffn_persist = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "attn_small")) {  // small-batch attention: 0 never, 1 by batch size, 2 / 4 force the key pieces
+    if (value != 0 && value != 1 && value != 2 && value != 4) return FFD_ERR_INVALID;
+    g_attn_small = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "small_wgs")) {  // most workgroups (row tiles x F splits) the small-M pair is used for
+    if (value < 0) return FFD_ERR_INVALID;
+    g_small_wgs = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "small_path")) {  // split out-proj + FFN pair for small M (0 = always the large-M kernels)
+    g_small_path = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_prio")) {  // raised wave priority outside the FFN main loop
@@ -627,7 +643,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
     if (qkv_attn) {
       // in-projection + attention in one launch: q/k/v never leave the CU (ffd_qkvattn.hip); in MIXED batch
       // element 0's workgroups also publish their recomputed K/V rows (caching.py:326-328)
-      const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L) : 1;
+      const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L, B) : 1;
       const float* pack = hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
       TIMED(FFD_K_ATTN, launch_qkv_attention(cur, pack, hpw, mode == PURE, tables ? kt : nullptr,
                                              tables ? vt : nullptr, mode == MIXED ? kt : nullptr,
@@ -639,8 +655,18 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
         HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
     }
-    TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-    TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
+    if (const int ns = small_path_splits(M, d, F)) {
+      // small M: out-proj + LN1 recomputed per F split, FFN partials + a deterministic reduce / LN2 launch
+      const size_t need = small_path_partial_floats(M, d, ns);
+      if (need > ctx->ffn_part_floats) {
+        if (int rc = dev_alloc(ctx, &ctx->ffn_part, need)) return rc;
+        ctx->ffn_part_floats = need;
+      }
+      TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
+    } else {
+      TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+      TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
+    }
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
       // straight into this layer's tables: head-major (1,H,L,hd) == table layout
@@ -1042,7 +1068,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   // (B, L, C) round trip less per step).  FreSca needs the whole score (FFT along L).
   const bool fuse_tail = g_fuse_tail && !ctx->fresca_on && m.kind != FFD_MODEL_MLP &&
                          unembed_sde_supported(m.n_channels, d) && (m.n_channels % 4 != 0 || elem_off % 4 == 0) &&
-                         (!z_inject || (reinterpret_cast<uintptr_t>(z_inject) % 16 == 0 && slab % 4 == 0));
+                         (!z_inject || m.n_channels % 4 != 0 ||  // float4 reads of the injected noise only when C % 4 == 0
+                          (reinterpret_cast<uintptr_t>(z_inject) % 16 == 0 && slab % 4 == 0));
   for (int j = 0; j < n_run; ++j) {
     const int i = first_step + j;
     int n_rec = -1;
@@ -1172,7 +1199,10 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
   const char* name = nullptr;
   switch (kernel_class) {
     case FFD_K_FFN:  // 4 d F FLOP per row; x in, y out, both weight matrices once
-      if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
+      if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
+        name = "k_oproj_ffn_split + k_ffn_reduce_ln", fl = 4.0 * M * d * F + 2.0 * M * d * d,
+        by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
+      else if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       break;
     case FFD_K_ATTN:  // in-projection (Q only on a pure-cache step) + QK^T + PV; x in, attention output out
       if (tr) {
@@ -1182,7 +1212,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       }
       break;
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
-      if (tr) name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
+      if (tr && !small_path_splits((int)M, m.d_model, m.dim_feedforward))
+        name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
     case FFD_K_LSTM_REC:
       if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out

@@ -667,7 +667,8 @@ hipError_t launch_unembed(const float* h, const float* Wu, const float* bu, floa
 hipError_t launch_unembed_sde(const float* h, const float* Wu, const float* bu, float* x, const float* z, const float* G,
                               SdeParams p, uint64_t seed, uint64_t elem_offset, uint32_t step, int B, int L, int C,
                               int D, hipStream_t s) {
-  if (!unembed_sde_supported(C, D) || !ptr16(h) || !ptr16(Wu) || !ptr16(x) || !ptr16(z)) return hipErrorInvalidValue;
+  if (!unembed_sde_supported(C, D) || !ptr16(h) || !ptr16(Wu)) return hipErrorInvalidValue;
+  if ((C & 3) == 0 && (!ptr16(x) || !ptr16(z))) return hipErrorInvalidValue;  // x / z quads
   if ((C & 3) == 0 && (elem_offset & 3)) return hipErrorInvalidValue;
   return launch_unembed_mfma<true>(h, Wu, bu, nullptr, x, z, G, p, seed, elem_offset, step, B * L, L, C, D, s);
 }

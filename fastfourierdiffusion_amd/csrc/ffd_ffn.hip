@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 int g_ffn_prio = 0;         // 1: waves outside their main loop run at raised priority (ffd_tune "ffn_prio")
 int g_ffn_dynamic = 0;      // 1: the persistent grid takes tiles from a device counter; 0: static round robin
 int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
-static int num_cus() {
+int num_cus() {
   static int n = 0;
   if (n == 0) {
     int dev = 0;

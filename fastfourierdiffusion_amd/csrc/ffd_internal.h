@@ -109,6 +109,14 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                          unsigned long long* stamp = nullptr, int* tile_ctr = nullptr);
 int ffn_tile_rows(int M);
+// Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
+// workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
+int small_path_splits(int M, int D, int F);
+size_t small_path_partial_floats(int M, int D, int NS);
+hipError_t launch_oproj_ffn_small(const float* attn, const float* xres, const LayerWeights& w, float* x1, float* P,
+                                  float* Y, int M, int D, int F, int NS, hipStream_t s);
+extern int g_small_path;
+extern int g_small_wgs;
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
 extern int g_ffn_stagger;
@@ -121,7 +129,10 @@ size_t attn_pack_floats(int D, int H, int hpw, int q_only);
 hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
                             hipStream_t s);
 bool qkv_attention_supported(int D, int hd);
-int qkv_attention_hpw(int D, int hd, int L);
+int qkv_attention_hpw(int D, int hd, int L, int B);
+int qkv_attention_small_split(int B, int H, int L);
+extern int g_attn_small;
+int num_cus();  // compute units of the current device (256 on MI355X); ffd_ffn.hip
 extern int g_attn_hpw;
 hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
                                 const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,

@@ -90,11 +90,17 @@ hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, i
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------
-template <int D, int HD, int QG, int NCT>
+//
+// SPLIT (small batches, e.g. the benchmark_cache.py harness at batch 1: B*H workgroups would leave most of the chip
+// idle and every wave walking 3 q-tiles x 6 key tiles in sequence): `qsplit` workgroups per (sample, head), each
+// projecting the whole head but attending only nwaves/kspl q-tiles, with the key range of a q-tile cut into `kspl`
+// pieces over the waves (flash-decoding).  The pieces (reference exponent, row sum, unnormalised output) meet in
+// LDS and are merged in piece order, so the result does not depend on timing.
+template <int D, int HD, int QG, int NCT, bool SPLIT = false>
 __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
-    int B, int L, int n_own, int q_only) {
+    int B, int L, int n_own, int q_only, int qsplit, int kspl) {
   constexpr int H = D / HD;
   constexpr int KST = (HD + 1) / 2;
   constexpr int KSX = (HD + 2) / 2;
@@ -111,9 +117,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.
   // All H heads of a sample read the same x rows, so they are placed on one XCD: x is fetched into one L2
   // once instead of into (up to) eight.
-  int b, h;
+  int b, h, qs = 0;
   {
-    const int pair = blockIdx.x;
+    int pair = blockIdx.x;
+    if constexpr (SPLIT) qs = pair % qsplit, pair /= qsplit;
     const int nmain = (B >> 3) * 8 * H;
     if (pair < nmain) {
       const int xcd = pair & 7, slot = pair >> 3;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   }
   __syncthreads();
   // MIXED: batch element 0 publishes its recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
-  if (kt_out != nullptr && b == 0) {
+  if (kt_out != nullptr && b == 0 && qs == 0) {
     for (int idx = threadIdx.x; idx < n_own * HD; idx += blockDim.x) {
       const int j = idx / HD, e = idx - j * HD;
       kt_out[(size_t)h * L * HD + idx] = kts[e * Lp + j];
@@ -287,7 +294,15 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   };
   const int QT = KT;
   const int d = D;
-  for (int qt0 = wave * QG; qt0 < QT; qt0 += nwaves * QG) {
+  // q-tiles of this wave: qt0 = q_first, q_first + q_step, ... < q_end; key tiles [t_lo, t_hi)
+  int q_first = wave * QG, q_step = nwaves * QG, q_end = QT, t_lo = 0, t_hi = KT;
+  if constexpr (SPLIT) {  // one (q-tile, key piece) per wave; exactly one trip so that every wave reaches the merge
+    const int qpw = nwaves / kspl, kps = (KT + kspl - 1) / kspl;
+    q_first = qs * qpw + wave / kspl, q_step = 1, q_end = q_first + 1;
+    t_lo = (wave % kspl) * kps, t_hi = min(KT, t_lo + kps);
+    if (q_first >= QT) t_hi = t_lo;  // ragged last workgroup: an empty piece
+  }
+  for (int qt0 = q_first; qt0 < q_end; qt0 += q_step) {
     float qf[QG][KSX], mref[QG];
     bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
     f32x2 lsum[QG], acc[QG][HP];
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
     }
 #pragma unroll 1
-    for (int t = 0; t < KT; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
       float kf[KSX];
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
@@ -346,12 +361,12 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
         // m_ref starts at 0 and usually stays there: |scores| <= 64 (log2 domain) neither overflow nor lose the row
         // to underflow, and the factor 2^-m_ref cancels in the normalisation whatever it is.
-        const bool refresh = (t == 0) ? (fabsf(bmx) > T) : (bmx > T);
+        const bool refresh = (t == t_lo) ? (fabsf(bmx) > T) : (bmx > T);
         if (__builtin_amdgcn_ballot_w64(refresh) != 0) ref_on = true;
         if (refresh) {
           const float delta = bmx;
           mref[g] += delta;
-          if (t != 0) {
+          if (t != t_lo) {
             const float corr = __builtin_amdgcn_exp2f(-delta);
             lsum[g] *= corr;
 #pragma unroll
@@ -387,6 +402,42 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         }
       }
     }
+    if constexpr (SPLIT) {
+      constexpr int PS = 2 + 2 * HP;  // per query row: reference exponent, row sum, unnormalised output
+      float* part = lds + (size_t)Lp * (8 + 4 * KST);  // [wave][32][PS]
+      float l = lsum[0].x + lsum[0].y;
+      l += __shfl_xor(l, 32);
+      float o[2 * HP];
+#pragma unroll
+      for (int e = 0; e < HP; ++e) {
+        float a0 = acc[0][e].x, a1 = acc[0][e].y;
+        o[2 * e] = a0 + __shfl_xor(a0, 32), o[2 * e + 1] = a1 + __shfl_xor(a1, 32);
+      }
+      if (half == 0) {
+        float* pw = part + (size_t)(wave * 32 + l31) * PS;
+        pw[0] = (t_lo < t_hi) ? mref[0] : -INFINITY;  // an empty piece weighs 2^-inf = 0 in the merge
+        pw[1] = l;
+#pragma unroll
+        for (int e = 0; e < 2 * HP; ++e) pw[2 + e] = o[e];
+      }
+      __syncthreads();
+      const int qpw = nwaves / kspl;
+      for (int idx = threadIdx.x; idx < qpw * 32 * HD; idx += blockDim.x) {
+        const int e = idx % HD, ql = (idx / HD) & 31, qi = idx / (HD * 32);
+        const int qtile = qs * qpw + qi, q = 32 * qtile + ql;
+        if (qtile >= QT || q >= L) continue;
+        const float* p0 = part + (size_t)(qi * kspl * 32 + ql) * PS;
+        float mx = -INFINITY;
+        for (int sp = 0; sp < kspl; ++sp) mx = fmaxf(mx, p0[(size_t)sp * 32 * PS]);
+        float lt = 0.f, ot = 0.f;
+        for (int sp = 0; sp < kspl; ++sp) {
+          const float* pp = p0 + (size_t)sp * 32 * PS;
+          const float wgt = __builtin_amdgcn_exp2f(pp[0] - mx);
+          lt = fmaf(pp[1], wgt, lt), ot = fmaf(pp[2 + e], wgt, ot);
+        }
+        out[((size_t)b * L + q) * d + h * HD + e] = ot / lt;
+      }
+    } else {
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       float l = lsum[g].x + lsum[g].y;
@@ -406,6 +457,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll
         for (int e = 0; e < HD; ++e) orow[e] = o[e];
       }
+    }
     }
   }
 }
@@ -778,8 +830,37 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
   if (nwaves > 4) nwaves = 4;
   if (cdiv(2 * KT, nwaves) > 8) return hipErrorInvalidValue;  // the projection loop is unrolled for <= 8 token tiles per wave
   hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x, awp, kt, vt,
-                     kt_out, vt_out, out, B, L, n_own, q_only);
+                     kt_out, vt_out, out, B, L, n_own, q_only, 1, 1);
   return hipGetLastError();
+}
+
+// small batches: 4 waves per workgroup, 4 / kspl q-tiles per workgroup, the key range of each cut into kspl pieces
+template <int D, int HD, int NCT>
+static hipError_t launch_split_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
+                                 float* vt_out, float* out, int B, int L, int n_own, int q_only, int kspl, hipStream_t s) {
+  constexpr int KST = (HD + 1) / 2, HP = (HD + 1) / 2;
+  const int KT = (L + 31) / 32;
+  if (cdiv(2 * KT, 4) > 8 || (kspl != 1 && kspl != 2 && kspl != 4)) return hipErrorInvalidValue;
+  const int qsplit = cdiv(KT, 4 / kspl);
+  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP)) * sizeof(float);
+  hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
+                     vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl);
+  return hipGetLastError();
+}
+
+int g_attn_small = 1;  // 0 never, 1 by batch size, 2 / 4 force that many key pieces (ffd_tune "attn_small")
+
+// Key pieces per q-tile of the small-batch split form, 0 when the one-workgroup-per-head(-pair) kernels run: the
+// split form projects a head once per q-split, which only pays while the chip is not full.
+int qkv_attention_small_split(int B, int H, int L) {
+  if (g_attn_small == 0 || L > 512) return 0;
+  if (g_attn_small == 2 || g_attn_small == 4) return g_attn_small;
+  const int QT = (L + 31) / 32;
+  // tools/sweep_small.py (ECG, H = 12, 6 q-tiles): four key pieces win while the grid stays under ~5/8 of the CUs
+  // (B <= 2), two pieces up to ~5/4 (B <= 8); beyond that the repeated projection costs more than the idle CUs
+  if (8L * B * H * QT <= 5L * num_cus()) return 4;
+  if (4L * B * H * cdiv(QT, 2) <= 5L * num_cus()) return 2;
+  return 0;
 }
 
 template <int D, int HD>
@@ -787,6 +868,9 @@ static hipError_t launch_dh(const float* x, const float* awp, int q_only, const 
                             float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s) {
   constexpr int NCTF = (3 * HD + 15) / 16;
   const int QT = (L + 31) / 32;
+  if (const int kspl = qkv_attention_small_split(B, D / HD, L))
+    return q_only ? launch_split_t<D, HD, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, kspl, s)
+                  : launch_split_t<D, HD, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, kspl, s);
   if (q_only) {
     if (QT == 1) return launch_t<D, HD, 1, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
     if (QT % 3 == 0) return launch_t<D, HD, 3, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
@@ -818,7 +902,8 @@ bool qkv_attention_supported(int D, int hd) {
 int g_attn_hpw = 0;  // 0 heuristic, 1 / 2 force heads per workgroup (ffd_tune "attn_hpw")
 
 // heads per workgroup the fused kernel uses for this shape (the caller passes the matching weight pack)
-int qkv_attention_hpw(int D, int hd, int L) {
+int qkv_attention_hpw(int D, int hd, int L, int B) {
+  if (qkv_attention_small_split(B, D / hd, L)) return 1;
   const bool mh2 = ((D == 72 && hd == 6) || (D == 60 && hd == 5) || (D == 48 && hd == 4)) && L <= 192;
   return (g_attn_hpw == 1 || !mh2) ? 1 : 2;
 }

@@ -246,17 +246,24 @@ def test_encoders_reference_tests(ffd, golden):
 
 
 # -------------------------------------------------------------- models -----
-@pytest.fixture(params=["auto", "unfused"])
+@pytest.fixture(params=["auto", "large", "unfused"])
 def variant(request, ffd):
-    """Kernel variants that must all meet the same parity bar: default heuristics (fused in-projection + attention
-    kernel) and the two-kernel projection / attention fallback ("unfused")."""
+    """Kernel variants that must all meet the same parity bar: default heuristics (at these small batches: the
+    q-/key-split fused attention kernel and the F-split out-proj + FFN pair), "large" (the kernels the heuristics pick
+    at large batches, forced: one workgroup per head (pair), k_linear_res_ln + k_ffn_ln) and the two-kernel
+    projection / attention fallback ("unfused")."""
     from fastfourierdiffusion_amd import _native as N
 
     lib = N.lib()
     if request.param == "unfused":
         assert lib.ffd_tune(b"attn_fused", 0) == 0
+    if request.param == "large":
+        assert lib.ffd_tune(b"attn_small", 0) == 0
+        assert lib.ffd_tune(b"small_path", 0) == 0
     yield request.param
     lib.ffd_tune(b"attn_fused", 1)
+    lib.ffd_tune(b"attn_small", 1)
+    lib.ffd_tune(b"small_path", 1)
 
 
 @pytest.mark.parametrize("c", cases.MODEL_CASES, ids=lambda c: c["name"])
@@ -934,7 +941,7 @@ def test_kernel_timing_and_work_accounting(ffd):
     c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
     m, sch = make_model(ffd, c)
     ctx = m._ctx()
-    B, L, Cn, NL, d, F = 4, c["L"], c["C"], c["NL"], c["d"], 2048
+    B, L, Cn, NL, d, F = 128, c["L"], c["C"], c["NL"], c["d"], 2048
     x = torch.randn(B, L, Cn, device="cuda")
     sch.set_timesteps(50)
     ts_c = (C.c_float * 50)(*sch.timesteps.tolist())
@@ -959,6 +966,10 @@ def test_kernel_timing_and_work_accounting(ffd):
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)).startswith(b"k_unembed_mfma")
     assert by.value == 4.0 * 512 * L * (d + 2 * Cn)
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) is None
+    # small M: the out-projection is absorbed into the F-split FFN pair (csrc/ffd_small.hip)
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_OUTPROJ, 1, 0, C.byref(fl), C.byref(by)) is None
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 1, 0, C.byref(fl), C.byref(by)).startswith(b"k_oproj_ffn_split")
+    assert fl.value == 4.0 * L * d * F + 2.0 * L * d * d
 
 
 @pytest.mark.parametrize("case", cases.AFFINE_FFT_CASES, ids=lambda c: f"L{c[0]}C{c[1]}")
@@ -1204,3 +1215,63 @@ def test_shard_invariance_with_and_without_batch_statistics(ffd):
     # the second half run on its own equals the oracle-defined behaviour of a B/2 batch; it may or may not equal the
     # slice of the big batch (the cutoff index is a batch statistic) -- only finiteness and shape are contractual
     assert torch.isfinite(full).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 8, 16, 32, 64, 96])
+def test_small_batch_split_ffn_matches_large_batch_kernels(ffd, B):
+    """Small M (the benchmark_cache.py harness's batch of one): out-proj + LN1 + FFN + LN2 run as an F-split pair of
+    launches (csrc/ffd_small.hip) instead of the two large-M kernels.  Same arithmetic, a different fp32 summation
+    order over the hidden dimension: the scores agree to 2e-6 relative, the split path is deterministic, and it stays
+    within the oracle tolerance on the way (the golden cases all run through it).  B = 1, 2, 3: 16 splits, two 16-unit
+    chunks per wave; B = 4: 8 x 4; B = 8: 4 x 8; B = 16: 2 x 16; B = 32: 4 x 8; B = 64: 2 x 16; B = 96: the large-M kernels."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4242))).cuda()
+    try:
+        assert lib.ffd_tune(b"small_path", 1) == 0
+        a = m(batch_of(x, 0.37))
+        a2 = m(batch_of(x, 0.37))
+        assert lib.ffd_tune(b"small_path", 0) == 0
+        b = m(batch_of(x, 0.37))
+    finally:
+        lib.ffd_tune(b"small_path", 1)
+    assert torch.equal(a, a2)
+    assert torch.isfinite(a).all()
+    assert rel_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kspl", [2, 4])
+def test_small_batch_attention_key_pieces(ffd, kspl):
+    """Small batches: each (sample, head) is spread over several workgroups and the key range of a q-tile over
+    `kspl` waves whose pieces merge in LDS (csrc/ffd_qkvattn.hip, SPLIT).  Against the one-workgroup-per-head-pair
+    kernel on the same inputs, in every cache mode (FULL -> PURE -> MIXED -> PURE), with tables published by the split
+    kernel and read by the other and vice versa."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    lib = N.lib()
+    L, C = c["L"], c["C"]
+    outs = {}
+    try:
+        for mode in (kspl, 0):
+            assert lib.ffd_tune(b"attn_small", mode) == 0
+            m, _ = make_model(ffd, c)
+            m.enable_caching()
+            m.cache.reset()
+            res = []
+            for j, n in enumerate([L, 0, 37, 0, L - 3]):
+                x = torch.from_numpy(next(synthetic.noise_stream((3, L, C), 1, 5100 + j))).cuda()
+                res.append(m(batch_of(x, 0.45), recompute_tokens=set(range(n)), step=j))
+            m.disable_caching()
+            res.append(m(batch_of(x, 0.45)))
+            outs[mode] = res
+    finally:
+        lib.ffd_tune(b"attn_small", 1)
+    for a, b in zip(outs[kspl], outs[0]):
+        assert torch.isfinite(a).all()
+        assert rel_err(a.cpu(), b.cpu()) < 2e-6

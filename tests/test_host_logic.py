@@ -412,3 +412,41 @@ def test_extraction_helpers_on_a_synthetic_run_directory(tmp_path):
         max_epochs, accumulate_grad_batches = 200, 4
 
     assert ex.get_training_params(DM(), TR())["num_training_steps"] == 5000
+
+
+def test_isa_lint_finds_dropped_accumulator_copies_and_clobbered_fragments(tmp_path):
+    """tools/check_mfma_operands.py on hand-made ISA: the two signatures of the hipcc 7.2 miscompile seen in
+    k_oproj_ffn_split (a VGPR -> AGPR copy turned into a no-op; a prefetched weight fragment member overwritten
+    while its siblings are still read) are reported, ordinary register reuse is not."""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_mfma_operands.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("""_Z3badv:
+	global_load_dwordx4 v[24:27], v[14:15], off
+                                        ; kill: def $agpr8 killed $vgpr44 killed $exec
+	v_accvgpr_read_b32 v25, a8
+	v_mfma_f32_16x16x4_f32 a[12:15], v24, v16, a[12:15]
+	v_mfma_f32_16x16x4_f32 a[12:15], v25, v16, a[12:15]
+	v_mfma_f32_16x16x4_f32 a[12:15], v26, v16, a[12:15]
+	s_endpgm
+""")
+    ok = tmp_path / "ok.s"
+    ok.write_text("""_Z2okv:
+	global_load_dwordx4 v[24:27], v[14:15], off
+	v_mfma_f32_16x16x4_f32 a[12:15], v24, v16, a[12:15]
+	v_max_f32_e32 v24, 0, v30
+	v_mfma_f32_16x16x4_f32 a[12:15], v25, v24, a[12:15]
+	v_mfma_f32_16x16x4_f32 a[12:15], v26, v24, a[12:15]
+	s_endpgm
+""")
+    r = subprocess.run([sys.executable, tool, str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "dropped accumulator copy" in r.stdout and "v25 overwritten" in r.stdout, r.stdout
+    r = subprocess.run([sys.executable, tool, str(ok)], capture_output=True, text=True)
+    assert r.returncode == 0 and "0 suspicious" in r.stdout, r.stdout
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="needs hipcc")
+def test_isa_lint_clean_on_every_kernel_source():
+    """make lint: the gfx950 ISA of every csrc/*.hip carries neither signature."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastfourierdiffusion_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "lint", "-j4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
