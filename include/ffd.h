@@ -290,7 +290,11 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
  *   "ffn_persist" = 1 | 0 | n                  fused FFN at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
  *   "ffn_dynamic" = 1 | 0                      persistent FFN: tiles handed out by a device counter, or a static partition;
- *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 as an F-split pair of launches (ffd_small.hip);
+ *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
+ *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most
+ *                                              workgroups the split form is used for (0 = heuristic);
+ *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
+ *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
  *   "ffn_prio" = 1 | 0                         fused FFN: raised wave priority outside the main loop;
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
  *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
