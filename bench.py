@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the opt-in split FFN keeps 6 bf16 products per fp32 one)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
@@ -70,6 +71,9 @@ def parse_args(argv=None):
     ap.add_argument("--ablation", action="store_true",
                     help="also run the reference harness's ablation grid (cmd/benchmark_cache.py:274-422) at B=1")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ffd_tune (experiments)")
+    ap.add_argument("--ffn-split", action="store_true",
+                    help="run with the opt-in bf16x3-split FFN (fp32-equivalent, NOT the reference's fp32 arithmetic): "
+                         "its own line, dtype 'bf16x3-split, fp32 accumulate'")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and the barrier / max-reduce "
                          "run over gloo (RCCL refuses two ranks on one device); the reported number is meaningless")
@@ -244,7 +248,9 @@ def roofline_entry(lib, ctx, N, cls, B, cache_hit, traffic_tab, key):
     name = name.decode()
     mfma = cls in (N.K_FFN, N.K_ATTN, N.K_LSTM_REC)
     sec = ms.value * 1e-3
-    if mfma:
+    if mfma and name == "k_ffn_ln_split":  # fp32-equivalent FLOP against the bf16 dense peak / 6 kept terms
+        ach, peak, unit = fl.value / sec / 1e12, PEAK_BF16_MFMA_TFLOPS / 6.0, "TFLOP/s"
+    elif mfma:
         ach, peak, unit = fl.value / sec / 1e12, PEAK_FP32_MFMA_TFLOPS, "TFLOP/s"
     else:
         ach, peak, unit = by.value / sec / 1e9, PEAK_HBM_GBS, "GB/s"
@@ -292,6 +298,8 @@ def main() -> None:
     for kv in args.tune:
         k, v = kv.split("=")
         assert N.lib().ffd_tune(k.encode(), int(v)) == 0, kv
+    if args.ffn_split:
+        assert N.lib().ffd_tune(b"ffn_split", 1) == 0
     model, sch, sd = build_model(device, args.workload)
     B, L, Cn = args.batch, model.max_len, model.n_channels
     n_total = 1000
@@ -342,7 +350,7 @@ def main() -> None:
                   f"samples/sec at 1000 diffusion steps, {args.workload}",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "bf16x3-split, fp32 accumulate (FFN); f32 elsewhere" if args.ffn_split else "f32", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload],
                    "batch_per_gpu": B, "global_batch": B * world, "diffusion_steps": n_total,
                    "cache": use_cache, "noise": "philox on device", "sharding": f"batch x{world}, no collectives"},
@@ -415,6 +423,33 @@ def main() -> None:
             model.disable_caching()
             out["cache_ratio"] = {"off_over_on": t_off / t_on, "ms_off": t_off * 1e3, "ms_on": t_on * 1e3,
                                   "batch": B, "note": "pure-cache steps (K/V projections skipped)"}
+        if not is_lstm and not use_cache and world == 1 and not args.ffn_split:
+            # Opt-in, reported next to the f32 line and never as `value`: the same steps with the FFN on the bf16
+            # matrix cores as a three-part / six-term split (fp32-equivalent to ~2e-7, passes the same goldens, but not
+            # the reference's fp32 FMA arithmetic).  python bench.py --ffn-split makes it the whole line.
+            def timed_split(on):
+                assert lib.ffd_tune(b"ffn_split", on) == 0
+                X3 = sampler.sample_prior(B, _sample_offset=offset)
+                nst = 100 if B * L <= 512 * 512 else 3
+                run_steps(model, X3, ts_c, n_total, step_size, 0, 10 if nst == 100 else 1, False, stream, offset)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                run_steps(model, X3, ts_c, n_total, step_size, 10, nst, False, stream, offset)
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - t1) / nst
+
+            try:
+                t_split = timed_split(1)
+                N.check(lib.ffd_kernel_timing_begin(ctx.handle, 1 << N.K_FFN, 3 * NLy), ctx.handle, "ffd_kernel_timing_begin")
+                run_steps(model, X, ts_c, n_total, step_size, 1, 3, False, stream, offset)
+                N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "ffd_kernel_timing_end")
+                rl = roofline_entry(lib, ctx, N, N.K_FFN, B, False, {}, key)
+            finally:
+                lib.ffd_tune(b"ffn_split", 0)
+            out["ffn_split_opt_in"] = {
+                "dtype": "bf16x3-split, fp32 accumulate (FFN); f32 elsewhere", "value": B / (1000.0 * t_split),
+                "unit": "samples/s", "ms_per_step": t_split * 1e3, "over_f32_line": (ms_per_step * 1e-3) / t_split,
+                "roofline": rl, "note": "off by default (ffd_tune ffn_split); peak = 2.5 PFLOP/s dense bf16 / 6 kept terms"}
         if args.workload == "ecg" and world == 1:
             # The reference's own harness regime (cmd/benchmark_cache.py:42-112,159-186): sample_batch_size = 1,
             # 10 samples x 100 steps, speedup = t_no_cache / t_cache -- next to the oracle's CPU ratio at B=1.

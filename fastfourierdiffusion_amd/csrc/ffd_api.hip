@@ -30,6 +30,7 @@ struct LstmLayer {
 
 struct LayerPacked {
   float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
+  float *w1s = nullptr, *w2s = nullptr;  // bf16x3 packs of the opt-in split FFN, made on first use
   float *aw_full = nullptr, *aw_q = nullptr;    // per-head packs of the fused in-projection + attention kernel
   float *aw_full2 = nullptr, *aw_q2 = nullptr;  // same, per pair of heads (two-head workgroups)
 };
@@ -185,6 +186,10 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "attn_small")) {  // small-batch attention: 0 never, 1 by batch size, 2 / 4 force the key pieces
     if (value != 0 && value != 1 && value != 2 && value != 4) return FFD_ERR_INVALID;
     g_attn_small = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_split")) {  // opt-in bf16x3-split FFN (not the reference's fp32 arithmetic; ffd_ffn_split.hip)
+    g_ffn_split = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "small_wgs")) {  // most workgroups (row tiles x F splits) the small-M pair is used for
@@ -476,6 +481,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
       HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
       HIPCHECK(launch_pack_w2rem(W(pre + "linear2.weight"), pk.w2r, d, F, s));
+      if (pk.w1s) HIPCHECK(launch_pack_ffn_split(W(pre + "linear1.weight"), W(pre + "linear2.weight"), pk.w1s, pk.w2s, d, F, s));
       LayerWeights& lw = ctx->layers[i];
       lw.in_w = in_w;
       lw.in_b = W(pre + "self_attn.in_proj_bias");
@@ -494,6 +500,8 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       lw.w1p = pk.w1p;
       lw.w2p = pk.w2p;
       lw.w2r = pk.w2r;
+      lw.w1s = pk.w1s;
+      lw.w2s = pk.w2s;
     }
   } else if (m.kind == FFD_MODEL_LSTM) {
     const bool first = ctx->lstm.empty();
@@ -634,6 +642,11 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
   float* cur = ctx->h0;  // layer input / residual
   float* alt = ctx->h1;
   auto proj_w = [&](int i) { return mode == PURE ? ctx->packed[i].q_wp : ctx->packed[i].in_wp; };
+  // opt-in: the FFN on the bf16 matrix cores as a three-part split (ffd_ffn_split.hip); takes every batch size, so
+  // that all parity cases exercise it when it is on
+  if (g_ffn_split && !ffn_split_supported(d, F))
+    return ctx->fail(FFD_ERR_UNSUPPORTED, "ffn_split needs d_model %% 4 == 0, d_model <= 96, dim_feedforward %% 128 == 0");
+  const bool split_ffn = g_ffn_split != 0;
   for (int i = 0; i < m.num_layers; ++i) {
     const LayerWeights& w = ctx->layers[i];
     const LayerPacked& pk = ctx->packed[i];
@@ -655,7 +668,15 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       if (mode == MIXED)  // store batch element 0's recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
         HIPCHECK(launch_kv_store(kreg, vreg, kt, vt, L, H, hd, n_rec, s));
     }
-    if (const int ns = small_path_splits(M, d, F)) {
+    if (split_ffn && pk.w1s == nullptr) {  // first use: make the packs
+      LayerPacked& pkm = ctx->packed[i];
+      if (int rc = dev_alloc(ctx, &pkm.w1s, w1split_bytes(d, F) / sizeof(float))) return rc;
+      if (int rc = dev_alloc(ctx, &pkm.w2s, w2split_bytes(d, F) / sizeof(float))) return rc;
+      HIPCHECK(launch_pack_ffn_split(w.w1, w.w2, pkm.w1s, pkm.w2s, d, F, s));
+      ctx->layers[i].w1s = pkm.w1s;
+      ctx->layers[i].w2s = pkm.w2s;
+    }
+    if (const int ns = split_ffn ? 0 : small_path_splits(M, d, F)) {
       // small M: out-proj + LN1 recomputed per F split, FFN partials + a deterministic reduce / LN2 launch
       const size_t need = small_path_partial_floats(M, d, ns);
       if (need > ctx->ffn_part_floats) {
@@ -665,7 +686,8 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
     } else {
       TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-      TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
+      if (split_ffn) TIMED(FFD_K_FFN, launch_ffn_ln_split(alt, w, cur, M, d, F, s));
+      else TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
     }
     if (mode == FULL) {
       // K,V of the layer OUTPUT for batch element 0 (cached_transformer.py:144-158), written
@@ -1199,7 +1221,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
   const char* name = nullptr;
   switch (kernel_class) {
     case FFD_K_FFN:  // 4 d F FLOP per row; x in, y out, both weight matrices once
-      if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
+      if (tr && g_ffn_split) name = "k_ffn_ln_split", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d) + 6.0 * (2.0 * d * F);
+      else if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
         name = "k_oproj_ffn_split + k_ffn_reduce_ln", fl = 4.0 * M * d * F + 2.0 * M * d * d,
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
       else if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
@@ -1212,7 +1235,7 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       }
       break;
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
-      if (tr && !small_path_splits((int)M, m.d_model, m.dim_feedforward))
+      if (tr && (g_ffn_split || !small_path_splits((int)M, m.d_model, m.dim_feedforward)))
         name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
     case FFD_K_LSTM_REC:
@@ -1292,7 +1315,13 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);  // random data
   HIPCHECK(hipGetLastError());
-  const int nwg = cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
+  const bool split = g_ffn_split && ctx->layers[0].w1s != nullptr;  // (packed by the first forward with ffn_split on)
+  if (g_ffn_split && !split) return ctx->fail(FFD_ERR_STATE, "ffn_split: run one forward first (the packs are made on first use)");
+  const int nwg = split ? cdiv(M, 64) : cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
+  auto launch = [&](unsigned long long* st) {
+    return split ? launch_ffn_ln_split(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st)
+                 : launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st, ctx->ffn_ctr);
+  };
   unsigned long long* stamps = nullptr;
   HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 8 * nwg));
   HIPCHECK(hipMemsetAsync(stamps, 0, sizeof(unsigned long long) * 8 * nwg, s));
@@ -1304,14 +1333,14 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   double elapsed = 0.0;
   while (elapsed < warm_seconds) {
     for (int i = 0; i < 50; ++i)
-      HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, nullptr, ctx->ffn_ctr));
+      HIPCHECK(launch(nullptr));
     HIPCHECK(hipEventRecord(e1, s));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
     elapsed = ms * 1e-3;
   }
-  HIPCHECK(launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, stamps, ctx->ffn_ctr));
+  HIPCHECK(launch(stamps));
   std::vector<unsigned long long> h(8 * (size_t)nwg);
   HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 8 * nwg, hipMemcpyDeviceToHost, s));
   HIPCHECK(hipStreamSynchronize(s));

@@ -53,6 +53,7 @@ struct LayerWeights {
   const float *w1p;     // dpack (F x d)
   const float *w2p;     // w2pack
   const float *w2r;     // w2rem (remainder rows d % 16 of linear2.weight, 4x4x1 MFMA A-operand order)
+  const void *w1s = nullptr, *w2s = nullptr;  // three-part bf16 packs of the opt-in split FFN (ffd_ffn_split.hip)
 };
 
 hipError_t launch_pack_dweight(const float* W, float* Wp, int N, int D, hipStream_t s);
@@ -117,6 +118,14 @@ hipError_t launch_oproj_ffn_small(const float* attn, const float* xres, const La
                                   float* Y, int M, int D, int F, int NS, hipStream_t s);
 extern int g_small_path;
 extern int g_small_wgs;
+// Opt-in bf16x3-split FFN (ffd_tune "ffn_split"; ffd_ffn_split.hip)
+extern int g_ffn_split;
+bool ffn_split_supported(int D, int F);
+size_t w1split_bytes(int D, int F);
+size_t w2split_bytes(int D, int F);
+hipError_t launch_pack_ffn_split(const float* W1, const float* W2, void* w1s, void* w2s, int D, int F, hipStream_t s);
+hipError_t launch_ffn_ln_split(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
+                               unsigned long long* stamp = nullptr);
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
 extern int g_ffn_stagger;

@@ -293,6 +293,10 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
  *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most
  *                                              workgroups the split form is used for (0 = heuristic);
+ *   "ffn_split" = 0 | 1                        OPT-IN, off by default: the FFN on the bf16 matrix cores, every fp32 operand cut
+ *                                              into three bf16 parts and the six largest cross terms kept (fp32-equivalent to
+ *                                              ~2e-7, passes the same goldens; NOT the reference's fp32 FMA arithmetic);
+ *                                              needs d_model <= 96, dim_feedforward % 128 == 0 (ffd_ffn_split.hip);
  *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
  *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
  *   "ffn_prio" = 1 | 0                         fused FFN: raised wave priority outside the main loop;

@@ -15,6 +15,11 @@ model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx()
 s = N.current_stream_ptr(dev)
 assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0 and ctx.lib.ffd_tune(b"ffn_dynamic", dynamic) == 0
+if os.environ.get("FFN_SPLIT") == "1":  # the opt-in bf16x3-split kernel (its packs are made by a first forward)
+    from fastfourierdiffusion_amd.utils.dataclasses import DiffusableBatch
+    assert ctx.lib.ffd_tune(b"ffn_split", 1) == 0
+    model(DiffusableBatch(X=torch.randn(2, model.max_len, model.n_channels, device=dev), y=None,
+                          timesteps=torch.full((2,), 0.5, device=dev)))
 cap = 4096
 raw = (C.c_uint64 * (8 * cap))()
 ghz, us, n = C.c_double(), C.c_double(), C.c_int()
