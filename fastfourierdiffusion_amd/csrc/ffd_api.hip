@@ -188,6 +188,11 @@ int ffd_tune(const char* key, int value) {
     g_attn_small = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "embed_threads")) {
+    if (value < 256) return FFD_ERR_INVALID;
+    g_embed_threads = value;
+    return FFD_OK;
+  }
   if (!strcmp(key, "ffn_split")) {  // opt-in bf16x3-split FFN (not the reference's fp32 arithmetic; ffd_ffn_split.hip)
     g_ffn_split = value ? 1 : 0;
     return FFD_OK;

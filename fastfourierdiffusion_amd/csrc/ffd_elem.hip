@@ -140,33 +140,48 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 // ---------------------------------------------------------------------------
 // embed: h[row][j] = be[j] + sum_c X[row][c] We[j][c] (+ pos[l][j]) + temb[b][j]
 // ---------------------------------------------------------------------------
-// Write-bound (4 (C + D) bytes per row, D >> C).  k_embed_reg (C <= 8): the grid is sized so that every thread keeps
-// ONE float4 column j of the output for its whole grid-stride loop (threads % (D/4) == 0): its 4 x C embedder weights,
-// bias and (shared) time embedding stay in registers, (b, l) of its row advance incrementally -- the loop body is the
-// row's x (C floats, float4 loads when C % 4 == 0; the D/4 threads of a row share them through L1), 4 C FMAs, one
-// positional float4 (L2-resident table) and one coalesced float4 store.  No LDS, no integer division in the loop.
+// Write-bound (4 (C + D) bytes per row, D >> C).  k_embed_reg (C <= 8): a thread owns ONE (position l, float4 column
+// j) of the output and walks the batch: its 4 x C embedder weights, bias, POSITIONAL float4 and (shared) time
+// embedding stay in registers, so the loop body is the row's x (C floats, float4 loads when C % 4 == 0; the D/4
+// threads of a row share them through L1), 4 C FMAs and one float4 store -- consecutive threads are consecutive
+// float4 of consecutive rows, every wave writes one contiguous 1 KiB run.  No LDS, no table reads, no integer
+// division in the loop; four samples per iteration keep four rows of loads in flight.
 template <bool XVEC>
 __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, const float* __restrict__ We,
                                                    const float* __restrict__ be, const float* __restrict__ pos,
                                                    const float* __restrict__ temb, int temb_stride,
-                                                   float* __restrict__ h, unsigned M, int L, int C, int D) {
+                                                   float* __restrict__ h, int B, int L, int C, int D, int nslices) {
   const unsigned D4 = (unsigned)D >> 2;
-  const unsigned T = gridDim.x * blockDim.x;          // multiple of D4 (launcher)
+  const unsigned LJ = (unsigned)L * D4;
   const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned rs = T / D4;                         // rows advanced per iteration
-  unsigned row = g / D4;
-  const int j = (int)(g - row * D4) << 2;
+  const unsigned slice = g / LJ;
+  if (slice >= (unsigned)nslices) return;
+  const unsigned lj = g - slice * LJ;
+  const unsigned l = lj / D4;
+  const int j = (int)(lj - l * D4) << 2;
   float4 w[8];
+  if (XVEC) {  // C = 4 or 8: the four weight rows j .. j+3 as float4 loads (8 instead of 32 per thread)
+    float wr[4][8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c)
-    w[c] = c < C ? float4{We[(j + 0) * C + c], We[(j + 1) * C + c], We[(j + 2) * C + c], We[(j + 3) * C + c]}
-                 : float4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(We + (size_t)(j + k) * C);
+      const float4 a2 = C > 4 ? *reinterpret_cast<const float4*>(We + (size_t)(j + k) * C + 4) : float4{0.f, 0.f, 0.f, 0.f};
+      wr[k][0] = a.x, wr[k][1] = a.y, wr[k][2] = a.z, wr[k][3] = a.w;
+      wr[k][4] = a2.x, wr[k][5] = a2.y, wr[k][6] = a2.z, wr[k][7] = a2.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[c] = float4{wr[0][c], wr[1][c], wr[2][c], wr[3][c]};
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      w[c] = c < C ? float4{We[(j + 0) * C + c], We[(j + 1) * C + c], We[(j + 2) * C + c], We[(j + 3) * C + c]}
+                   : float4{0.f, 0.f, 0.f, 0.f};
+  }
   const float4 bias = *reinterpret_cast<const float4*>(be + j);
-  unsigned b = row / (unsigned)L, l = row - b * (unsigned)L;
-  const unsigned qb = rs / (unsigned)L, rl = rs - qb * (unsigned)L;
+  const float4 p = pos ? *reinterpret_cast<const float4*>(pos + (size_t)l * D + j) : float4{0.f, 0.f, 0.f, 0.f};
   const float4 t0 = *reinterpret_cast<const float4*>(temb + j);  // the shared time embedding (temb_stride == 0)
-  auto load_x = [&](unsigned rw, float (&xv)[8]) {
-    const float* x = X + (size_t)rw * C;
+  auto load_x = [&](int b, float (&xv)[8]) {
+    const float* x = X + ((size_t)b * L + l) * C;
     if (XVEC) {
       const float4 a = *reinterpret_cast<const float4*>(x);
       xv[0] = a.x, xv[1] = a.y, xv[2] = a.z, xv[3] = a.w;
@@ -179,36 +194,27 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
       for (int c = 0; c < 8; ++c) xv[c] = c < C ? x[c] : 0.f;
     }
   };
-  auto emit = [&](unsigned rw, unsigned bb, unsigned ll, const float (&xv)[8], float4 p) {
+  auto emit = [&](int b, const float (&xv)[8]) {
     float4 v = bias;
 #pragma unroll
     for (int c = 0; c < 8; ++c)
       if (c < C) v.x = fmaf(xv[c], w[c].x, v.x), v.y = fmaf(xv[c], w[c].y, v.y), v.z = fmaf(xv[c], w[c].z, v.z), v.w = fmaf(xv[c], w[c].w, v.w);
     if (pos) v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
-    const float4 t = temb_stride ? *reinterpret_cast<const float4*>(temb + (size_t)bb * temb_stride + j) : t0;
-    *reinterpret_cast<float4*>(h + (size_t)rw * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
+    const float4 t = temb_stride ? *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j) : t0;
+    *reinterpret_cast<float4*>(h + ((size_t)b * L + l) * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
   };
-  auto advance = [&]() {
-    row += rs, l += rl, b += qb;
-    if (l >= (unsigned)L) l -= (unsigned)L, ++b;
-  };
-  // two rows per iteration: both rows' loads are in flight before the first store
-  while (row < M) {
-    float xa[8], xb[8];
-    const unsigned r0 = row, b0 = b, l0 = l;
-    load_x(r0, xa);
-    const float4 p0 = pos ? *reinterpret_cast<const float4*>(pos + (size_t)l0 * D + j) : float4{0.f, 0.f, 0.f, 0.f};
-    advance();
-    const bool two = row < M;
-    const unsigned r1 = row, b1 = b, l1 = l;
-    float4 p1{0.f, 0.f, 0.f, 0.f};
-    if (two) {
-      load_x(r1, xb);
-      if (pos) p1 = *reinterpret_cast<const float4*>(pos + (size_t)l1 * D + j);
-      advance();
-    }
-    emit(r0, b0, l0, xa, p0);
-    if (two) emit(r1, b1, l1, xb, p1);
+  int b = (int)slice;
+  for (; b + 3 * nslices < B; b += 4 * nslices) {
+    float xa[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_x(b + u * nslices, xa[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) emit(b + u * nslices, xa[u]);
+  }
+  for (; b < B; b += nslices) {
+    float xa[8];
+    load_x(b, xa);
+    emit(b, xa);
   }
 }
 
@@ -244,21 +250,22 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
   }
 }
 
+int g_embed_threads = 262144;  // ffd_tune "embed_threads": threads the embed grid aims at (tools/probes/embed_sweep.py: 114 us at 256 k, 118 at 512 k, 137 at 128 k on the config-5 shape)
+
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
                         int temb_stride, float* h, int B, int L, int C, int D, hipStream_t s) {
   const unsigned M = (unsigned)B * (unsigned)L;
   const unsigned total4 = (unsigned)((size_t)M * D / 4);
   if (C <= 8 && D % 4 == 0) {
-    // threads = blocks * 256 must be a multiple of D/4: blocks = multiple of (D/4) / gcd(D/4, 256)
-    unsigned D4 = (unsigned)D / 4, gcd = D4, r = 256;
-    while (r) { const unsigned t = gcd % r; gcd = r; r = t; }
-    const unsigned unit = D4 / gcd;
-    unsigned blocks = (total4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    blocks = ((blocks + unit - 1) / unit) * unit;
-    const bool xvec = (C == 4 || C == 8) && (reinterpret_cast<uintptr_t>(X) & 15) == 0;
-    if (xvec) hipLaunchKernelGGL(k_embed_reg<true>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, M, L, C, D);
-    else hipLaunchKernelGGL(k_embed_reg<false>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, M, L, C, D);
+    // one thread per (l, float4 column) and batch slice: as many slices as give ~512 k threads
+    const unsigned LJ = (unsigned)L * (unsigned)(D / 4);
+    int nslices = (int)((unsigned)g_embed_threads / LJ);
+    if (nslices < 1) nslices = 1;
+    if (nslices > B) nslices = B;
+    const unsigned blocks = (unsigned)(((size_t)nslices * LJ + 255) / 256);
+    const bool xvec = (C == 4 || C == 8) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(We)) & 15) == 0;
+    if (xvec) hipLaunchKernelGGL(k_embed_reg<true>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices);
+    else hipLaunchKernelGGL(k_embed_reg<false>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices);
     return hipGetLastError();
   }
   unsigned blocks = (total4 + 255) / 256;
