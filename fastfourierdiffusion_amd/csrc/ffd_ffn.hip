@@ -275,31 +275,56 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63;
     // acc = true: add to what the buffer holds (row stride st), else overwrite
+    // (a lane's four accumulator registers are four consecutive columns of one row: whole float4 where the row stride
+    //  allows -- the persistent form's S2 images -- so the epilogue, which crawls beside the partner workgroup's
+    //  MFMA stream, is a quarter of the LDS instructions)
     auto put_partial = [&](float* dst, int st, bool acc) {
+      const bool vec = (st & 3) == 0;  // compile-time after inlining (st is SX or S2)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int c = 16 * ct + 4 * (lane_e >> 4) + r;
-            if (c < D) {
-              float* q = &dst[(16 * mb + (lane_e & 15)) * st + c];
-              *q = acc ? *q + yacc[ct][mb][r] : yacc[ct][mb][r];
+        for (int mb = 0; mb < MB; ++mb) {
+          const int c0 = 16 * ct + 4 * (lane_e >> 4);
+          float* q0 = &dst[(16 * mb + (lane_e & 15)) * st + c0];
+          if (vec && c0 + 3 < D) {
+            float4* q4 = reinterpret_cast<float4*>(q0);
+            float4 o = float4{yacc[ct][mb][0], yacc[ct][mb][1], yacc[ct][mb][2], yacc[ct][mb][3]};
+            if (acc) {
+              const float4 a = *q4;
+              o = float4{a.x + o.x, a.y + o.y, a.z + o.z, a.w + o.w};
             }
+            *q4 = o;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c0 + r < D) q0[r] = acc ? q0[r] + yacc[ct][mb][r] : yacc[ct][mb][r];
           }
+        }
       if (NG > 0 && (lane_e >> 4) < NGA) {  // quarter q handles remainder group g = q
         const int g = lane_e >> 4;
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+        for (int mb = 0; mb < MB; ++mb) {
+          float v[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float v = 0.f;
+            v[i] = 0.f;
 #pragma unroll
-            for (int gg = 0; gg < NGA; ++gg) v = (gg == g) ? yrem[gg][mb][i] : v;
-            float* q = &dst[(16 * mb + (lane_e & 15)) * st + 16 * CT + 4 * g + i];
-            *q = acc ? *q + v : v;
+            for (int gg = 0; gg < NGA; ++gg) v[i] = (gg == g) ? yrem[gg][mb][i] : v[i];
           }
+          float* q0 = &dst[(16 * mb + (lane_e & 15)) * st + 16 * CT + 4 * g];
+          if (vec) {
+            float4* q4 = reinterpret_cast<float4*>(q0);
+            float4 o = float4{v[0], v[1], v[2], v[3]};
+            if (acc) {
+              const float4 a = *q4;
+              o = float4{a.x + o.x, a.y + o.y, a.z + o.z, a.w + o.w};
+            }
+            *q4 = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q0[i] = acc ? q0[i] + v[i] : v[i];
+          }
+        }
       }
     };
     if (wave == 0) put_partial(xs, SX, true);
@@ -315,6 +340,54 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
     const int row = tid_e / TPR, sub = tid_e % TPR;
     const int m = m0 + row;
+    if constexpr (DMA && D % 4 == 0) {
+      // whole float4 columns c4 = sub, sub + TPR, ... (images with 16-byte aligned rows)
+      constexpr int NV = cdiv(D / 4, TPR);
+      float4 v4[NV];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c4 = sub + i * TPR;
+        v4[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (c4 < D / 4) {
+          float4 v = *reinterpret_cast<const float4*>(&xs[row * SX + 4 * c4]);
+#pragma unroll
+          for (int k = 0; k < NRED; ++k) {
+            const float4 p = *reinterpret_cast<const float4*>(&red[(k * R + row) * S2 + 4 * c4]);
+            v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
+          }
+          const float4 bq = *reinterpret_cast<const float4*>(b2 + 4 * c4);
+          v.x += bq.x, v.y += bq.y, v.z += bq.z, v.w += bq.w;
+          sum += (v.x + v.y) + (v.z + v.w);
+          v4[i] = v;
+        }
+      }
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      const float mean = sum * (1.0f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (sub + i * TPR < D / 4) {
+          const float a = v4[i].x - mean, b = v4[i].y - mean, c = v4[i].z - mean, d = v4[i].w - mean;
+          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c, c, ss), ss = fmaf(d, d, ss);
+        }
+#pragma unroll
+      for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+      if (m < M) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+          const int c4 = sub + i * TPR;
+          if (c4 < D / 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gam + 4 * c4), e4 = *reinterpret_cast<const float4*>(bet + 4 * c4);
+            *reinterpret_cast<float4*>(Y + (size_t)m * D + 4 * c4) =
+                float4{(v4[i].x - mean) * rstd * g4.x + e4.x, (v4[i].y - mean) * rstd * g4.y + e4.y,
+                       (v4[i].z - mean) * rstd * g4.z + e4.z, (v4[i].w - mean) * rstd * g4.w + e4.w};
+          }
+        }
+      }
+    } else {
     float vals[cdiv(D, TPR)];
     float sum = 0.f;
 #pragma unroll
@@ -352,6 +425,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
         if (c < D) Y[(size_t)m * D + c] = (vals[i] - mean) * rstd * gam[c] + bet[c];
       }
     }
+    }
     if (stamp) {
       if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
       ++st_tiles;
@@ -372,7 +446,8 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   if (stamp && threadIdx.x == 0) {
     unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
     o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
-    o[6] = __builtin_amdgcn_s_memrealtime(), o[7] = (unsigned long long)st_tiles;
+    o[6] = __builtin_amdgcn_s_memrealtime();
+    o[7] = (unsigned long long)st_tiles | ((unsigned long long)__smid() << 32);  // + which CU (xcc, se, cu) it ran on
   }
 }
 
@@ -403,11 +478,12 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     const int target = 2 * 256;
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
-  // With two resident workgroups per CU and at least two rounds of tiles, de-phase the pair by about one
-  // prologue + epilogue so that one workgroup's non-MFMA phases run under the other's main loop
-  // (measured 469 -> 457 us on the 95744 x 72 x 2048 shape, tools/sweep_stagger.py).
-  const int stagger = (g_ffn_stagger >= 0 ? g_ffn_stagger : (mb == 4 && cdiv(M, 64) >= 4 * 256) ? 11 * D : 0) |
-                      (g_ffn_prio ? 0x40000000 : 0);
+  // Start stagger of the odd wave slot (ffd_tune "ffn_stagger", x64 cycles): 0.  Round 1 de-phased the two resident
+  // workgroups of a CU by 11 D x 64 cycles (469 -> 457 us then); with the persistent grid and the float4 epilogue the
+  // ECG step is fastest without it (5.89 ms against 5.92 at 792, 5.98 at 2900: tools/probes/step_ab.py).  The per-CU
+  // timeline (tools/ffn_timeline.py) shows why de-phasing cannot help: of the two workgroups of a CU one gets the
+  // issue slots (3 tiles by 365 us), the other trails (440 us) -- 73 us per tile shared, 71 alone.
+  const int stagger = (g_ffn_stagger >= 0 ? g_ffn_stagger : 0) | (g_ffn_prio ? 0x40000000 : 0);
   dim3 block(256);
   // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
   const int resident = num_cus() * (mb == 4 ? 2 : 1) * (g_ffn_persist > 0 ? g_ffn_persist : 1);

@@ -24,7 +24,10 @@ cap = 4096
 raw = (C.c_uint64 * (8 * cap))()
 ghz, us, n = C.c_double(), C.c_double(), C.c_int()
 N.check(ctx.lib.ffd_probe_ffn_clock(ctx.handle, B, 1.0, C.byref(ghz), C.byref(us), raw, cap, C.byref(n), s), ctx.handle, "probe")
-r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value].astype(np.float64)
+ru = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value]
+cu = (ru[:, 7] >> np.uint64(32)).astype(np.int64)  # (xcc, se, cu) of the workgroup
+r = ru.astype(np.float64)
+r[:, 7] = (ru[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 t0 = r[:, 2].min()
 q = lambda a: [round(float(v), 2) for v in np.percentile(a, [0, 10, 50, 90, 100])]
 tk = 0.01  # us per tick
@@ -34,4 +37,18 @@ out = {"B": B, "persist": persist, "dynamic": dynamic, "workgroups": int(n.value
        "first_prologue_us": q((r[:, 3] - r[:, 2]) * tk), "first_main_loop_us": q((r[:, 4] - r[:, 3]) * tk),
        "first_epilogue_us": q((r[:, 5] - r[:, 4]) * tk), "main_loops_total_us": q(r[:, 1] * tk),
        "lifetime_us": q((r[:, 6] - r[:, 2]) * tk), "percentiles": [0, 10, 50, 90, 100]}
+# per CU: how many workgroups it hosted, when its last one left, how far apart its workgroups started
+cus = {}
+for i in range(len(cu)):
+    cus.setdefault(int(cu[i]), []).append(i)
+last = np.array([max((r[i, 6] - t0) * tk for i in v) for v in cus.values()])
+cnt = np.array([len(v) for v in cus.values()])
+tiles_cu = np.array([sum(r[i, 7] for i in v) for v in cus.values()])
+out["cus_used"] = len(cus)
+out["workgroups_per_cu"] = q(cnt)
+out["tiles_per_cu"] = q(tiles_cu)
+out["cu_last_exit_us"] = q(last)
+late = [k for k, v in cus.items() if max((r[i, 6] - t0) * tk for i in v) > np.percentile(last, 85)]
+out["late_cus_tiles"] = sorted(float(sum(r[i, 7] for i in cus[k])) for k in late)[:40]
+out["late_cus_workgroups"] = sorted(len(cus[k]) for k in late)[:40]
 print(json.dumps(out))
