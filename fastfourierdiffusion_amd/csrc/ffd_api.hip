@@ -1322,7 +1322,7 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   HIPCHECK(hipGetLastError());
   const bool split = g_ffn_split && ctx->layers[0].w1s != nullptr;  // (packed by the first forward with ffn_split on)
   if (g_ffn_split && !split) return ctx->fail(FFD_ERR_STATE, "ffn_split: run one forward first (the packs are made on first use)");
-  const int nwg = split ? cdiv(M, 64) : cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
+  const int nwg = split ? (cdiv(M, 64) < num_cus() ? cdiv(M, 64) : num_cus()) : cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
   auto launch = [&](unsigned long long* st) {
     return split ? launch_ffn_ln_split(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st)
                  : launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st, ctx->ffn_ctr);

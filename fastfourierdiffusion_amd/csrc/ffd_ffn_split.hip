@@ -11,7 +11,8 @@
 // It is NOT the arithmetic of the reference (an fp32 FMA chain), so it never runs unless asked for, and bench.py
 // reports it on its own line (dtype "bf16x3-split, fp32 accumulate").
 //
-// Structure (one workgroup = 64 rows, 4 waves, one workgroup per CU -- the kernel uses the whole register file):
+// Structure (a tile = 64 rows; 4 waves, one workgroup per CU walking tiles blockIdx.x, += gridDim.x -- the kernel uses
+// the whole register file):
 //   * the X tile is split once into three bf16 planes in LDS (B operand of GEMM1, 8 consecutive k per lane);
 //   * wave w owns hidden chunks c = w, w + 4, ... (32 units each) for all four 16-row subtiles, its W1 / W2 fragments
 //     (pre-split and pre-permuted by k_pack_w*_split, coalesced 16-byte loads) in registers, each set reloaded
@@ -50,14 +51,22 @@ __device__ __forceinline__ f32x4 mfma_bf16(uint4 a, uint4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// GEMM1's K = d_model in 32-wide bf16 steps.  A remainder of 4, 8 or 12 columns (d = 72: 8) is NOT padded to a 32-wide
+// step (three quarters zeros, 6 MFMAs of 16 cycles) but runs as d%32/4 exact-fp32 16x16x4 steps (32 cycles each) into
+// the same accumulators: fewer matrix cycles, a third of the fragment bytes, and those terms are exact.
+constexpr __host__ __device__ int split_rf(int D) { return (D >= 32 && D % 32 != 0 && D % 32 <= 12) ? (D % 32) / 4 : 0; }
+constexpr __host__ __device__ int split_ks(int D) { return split_rf(D) ? D / 32 : cdiv(D, 32); }
+
 // ---- weight packs ------------------------------------------------------------------------------------
-// w1s: linear1.weight (F x D) as the A operand of H^T = W1 X^T, K padded to 32 KS:
+// w1s: linear1.weight (F x D) as the A operand of H^T = W1 X^T, K in KS = split_ks(D) steps of 32 (zero past D):
 //   [c = F/32][t 2][s KS][p 3][lane 64][j 8] bf16 = part_p(W1[32 c + 16 t + (lane & 15)][32 s + 8 (lane >> 4) + j])
+// w1r: its fp32 K remainder (split_rf(D) steps of 4), A operand of v_mfma_f32_16x16x4_f32:
+//   [c][lane 64][t 2][step 4] float = W1[32 c + 16 t + (lane & 15)][32 KS + 4 step + (lane >> 4)]   (0 for step >= RF)
 // w2s: linear2.weight (D x F) as the A operand of Y^T += W2 H^T with the GEMM1 accumulators as B:
 //   [c][ct = ceil(D/16)][p 3][lane][j] = part_p(W2[16 ct + (lane & 15)][32 c + hid(lane >> 4, j)]),
 //   hid(q, j) = 4 q + j (j < 4: tile t = 0, register j) | 16 + 4 q + j - 4 (tile t = 1)
 __global__ void k_pack_w1_split(const float* __restrict__ W1, uint16_t* __restrict__ out, int D, int F) {
-  const int KS = cdiv(D, 32);
+  const int KS = split_ks(D);
   const size_t total = (size_t)(F / 32) * 2 * KS * 3 * 64 * 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int j = i & 7, lane = (i >> 3) & 63;
@@ -70,6 +79,15 @@ __global__ void k_pack_w1_split(const float* __restrict__ W1, uint16_t* __restri
     const int f = 32 * c + 16 * t + (lane & 15), k = 32 * s + 8 * (lane >> 4) + j;
     const float v = k < D ? plane_of(W1[(size_t)f * D + k], p) : 0.f;
     out[i] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
+  }
+}
+__global__ void k_pack_w1_rem(const float* __restrict__ W1, float* __restrict__ out, int D, int F) {
+  const int KS = split_ks(D), RF = split_rf(D);
+  const size_t total = (size_t)(F / 32) * 64 * 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int step = i & 3, t = (i >> 2) & 1, lane = (i >> 3) & 63, c = (int)(i >> 9);
+    const int f = 32 * c + 16 * t + (lane & 15), k = 32 * KS + 4 * step + (lane >> 4);
+    out[i] = (step < RF && k < D) ? W1[(size_t)f * D + k] : 0.f;
   }
 }
 __global__ void k_pack_w2_split(const float* __restrict__ W2, uint16_t* __restrict__ out, int D, int F) {
@@ -88,11 +106,15 @@ __global__ void k_pack_w2_split(const float* __restrict__ W2, uint16_t* __restri
   }
 }
 
-size_t w1split_bytes(int D, int F) { return (size_t)(F / 32) * 2 * cdiv(D, 32) * 3 * 64 * 16; }
+size_t w1split_bytes(int D, int F) {  // the bf16 fragments, then (16-byte aligned) the fp32 remainder fragments
+  return (size_t)(F / 32) * 2 * split_ks(D) * 3 * 64 * 16 + (size_t)(F / 32) * 64 * 32;
+}
+static size_t w1rem_offset_bytes(int D, int F) { return (size_t)(F / 32) * 2 * split_ks(D) * 3 * 64 * 16; }
 size_t w2split_bytes(int D, int F) { return (size_t)(F / 32) * cdiv(D, 16) * 3 * 64 * 16; }
 
 hipError_t launch_pack_ffn_split(const float* W1, const float* W2, void* w1s, void* w2s, int D, int F, hipStream_t s) {
   hipLaunchKernelGGL(k_pack_w1_split, dim3(256), dim3(256), 0, s, W1, (uint16_t*)w1s, D, F);
+  hipLaunchKernelGGL(k_pack_w1_rem, dim3(64), dim3(256), 0, s, W1, (float*)((char*)w1s + w1rem_offset_bytes(D, F)), D, F);
   hipLaunchKernelGGL(k_pack_w2_split, dim3(256), dim3(256), 0, s, W2, (uint16_t*)w2s, D, F);
   return hipGetLastError();
 }
@@ -100,13 +122,15 @@ hipError_t launch_pack_ffn_split(const float* W1, const float* W2, void* w1s, vo
 // ---- the kernel ----------------------------------------------------------------------------------------
 template <int D>
 struct SplitGeom {
-  static constexpr int KS = cdiv(D, 32);         // 32-wide k-steps of GEMM1
+  static constexpr int KS = split_ks(D);         // 32-wide bf16 k-steps of GEMM1
+  static constexpr int RF = split_rf(D);         // + exact-fp32 remainder steps of 4
   static constexpr int KP = 32 * KS;
+  static constexpr int XRS = 4 * RF + 1;         // floats per row of the fp32 remainder image (odd: conflict-free)
   static constexpr int CT = cdiv(D, 16);         // 16-wide column tiles of Y
   static constexpr int XS = 2 * KP + 16;         // bytes per row of an X plane (odd multiple of 16: conflict-free b128 reads)
   static constexpr int PLANE = 64 * XS;
   static constexpr int RS = 16 * CT + 4;         // floats per row of a reduction image
-  static constexpr size_t lds = (size_t)3 * PLANE + (size_t)2 * 64 * RS * sizeof(float);
+  static constexpr size_t lds = (size_t)3 * PLANE + (size_t)2 * 64 * RS * sizeof(float) + (size_t)64 * XRS * sizeof(float);
 };
 
 template <int D>
@@ -117,17 +141,19 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
                                                          int F, unsigned long long* __restrict__ stamp) {
   // stamp (ffd_probe_ffn_clock only, nullptr otherwise): the 8 x u64 record of k_ffn_ln (ffd_ffn.hip)
   using G = SplitGeom<D>;
-  constexpr int KS = G::KS, KP = G::KP, CT = G::CT, XS = G::XS, PLANE = G::PLANE, RS = G::RS;
+  constexpr int KS = G::KS, KP = G::KP, CT = G::CT, XS = G::XS, PLANE = G::PLANE, RS = G::RS, RF = G::RF, XRS = G::XRS;
+  constexpr int DB = RF ? KP : D;  // columns that live in the bf16 planes
   constexpr int D4 = D / 4;
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* ximg = smem;                                        // [p 3][row 64][XS bytes]
   float* red = reinterpret_cast<float*>(smem + 3 * PLANE);           // [2][row 64][RS]
+  float* xrem = red + 2 * 64 * RS;                                   // [row 64][XRS]: fp32 columns DB .. D - 1
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = lane & 15, q = lane >> 4;
-  const int m0 = blockIdx.x * 64;
-  const int rows_valid = min(64, M - m0);
+  const int ntiles = (M + 63) >> 6;
   const int ncw = F / 128;  // chunks per wave
+  const float4* W1r = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(W1s) + (size_t)(F / 32) * 2 * KS * 3 * 64 * 16);
   const unsigned long long st_entry = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   // ---- this wave's fragments of a chunk: W1 [t][s][p] + the bias quads of the two hidden tiles; W2 [ct][p] ----
@@ -136,6 +162,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
   // (A second copy of W1 requested a whole chunk ahead was slower, 45 against 41 us per tile: the waits are not
   // latency -- every CU streams 57 GB/s of weights out of L2 here -- and 464 registers brought AGPR shuffling.)
   uint4 w1[2][KS][3], w2[CT][3];
+  float4 w1r[2];  // fp32 remainder fragments: [t] . {step 0..3}
   float4 ba, bb;
   float4 ban, bbn;  // the next chunk's bias quads (the current ones are still needed when W1 is reloaded)
   auto load_w1_next = [&](int i) {
@@ -147,6 +174,10 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
       for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int p = 0; p < 3; ++p) w1[t][s][p] = p1[((t * KS + s) * 3 + p) * 64];
+    if constexpr (RF > 0) {
+      const float4* pr = W1r + ((size_t)c * 64 + lane) * 2;
+      w1r[0] = pr[0], w1r[1] = pr[1];
+    }
     ban = *reinterpret_cast<const float4*>(b1 + 32 * c + 4 * q);
     bbn = *reinterpret_cast<const float4*>(b1 + 32 * c + 16 + 4 * q);
   };
@@ -163,31 +194,50 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
   load_w2(0);
 
   // ---- X tile -> three bf16 planes in LDS (rows past M repeat the last row; k in [D, KP) is zero) ----
-  for (int f = threadIdx.x; f < 64 * D4; f += 256) {
-    const int row = f / D4, c4 = f - row * D4;
-    const float4 x = *reinterpret_cast<const float4*>(X + (size_t)(m0 + min(row, rows_valid - 1)) * D + 4 * c4);
-    uint32_t a1, a2, a3, c1, c2, c3;
-    split3(x.x, x.y, a1, a2, a3);
-    split3(x.z, x.w, c1, c2, c3);
-    unsigned char* dst = ximg + row * XS + c4 * 8;
-    *reinterpret_cast<uint2*>(dst) = uint2{a1, c1};
-    *reinterpret_cast<uint2*>(dst + PLANE) = uint2{a2, c2};
-    *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{a3, c3};
-  }
-  if constexpr (KP > D) {
+  // Persistent over tiles (one workgroup per CU): the next tile's rows are requested into registers when the main loop
+  // ends and converted into the (single) image after the epilogue, so a tile boundary costs the epilogue + the
+  // conversion instead of a launch-time prologue with its exposed load latency (3.1 us per tile before).
+  constexpr int NXP = cdiv(64 * D4, 256);
+  float4 xpre[NXP];
+  auto stage_load = [&](int t) {
+    const int rv = min(64, M - t * 64);
+#pragma unroll
+    for (int u = 0; u < NXP; ++u) {
+      const int f = threadIdx.x + 256 * u;
+      const int row = f / D4, c4 = f - row * D4;
+      if (f < 64 * D4) xpre[u] = *reinterpret_cast<const float4*>(X + (size_t)(t * 64 + min(row, rv - 1)) * D + 4 * c4);
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int u = 0; u < NXP; ++u) {
+      const int f = threadIdx.x + 256 * u;
+      const int row = f / D4, c4 = f - row * D4;
+      if (f >= 64 * D4) continue;
+      const float4 x = xpre[u];
+      if (RF > 0 && 4 * c4 >= DB) {  // the fp32 remainder columns
+        float* d = xrem + row * XRS + (4 * c4 - DB);
+        d[0] = x.x, d[1] = x.y, d[2] = x.z, d[3] = x.w;
+        continue;
+      }
+      uint32_t a1, a2, a3, c1, c2, c3;
+      split3(x.x, x.y, a1, a2, a3);
+      split3(x.z, x.w, c1, c2, c3);
+      unsigned char* dst = ximg + row * XS + c4 * 8;
+      *reinterpret_cast<uint2*>(dst) = uint2{a1, c1};
+      *reinterpret_cast<uint2*>(dst + PLANE) = uint2{a2, c2};
+      *reinterpret_cast<uint2*>(dst + 2 * PLANE) = uint2{a3, c3};
+    }
+  };
+  int tile = blockIdx.x;
+  stage_load(tile);
+  if constexpr (RF == 0 && KP > D) {
     constexpr int PZ = (KP - D) / 4;  // 8-byte units of padding per row
     for (int f = threadIdx.x; f < 3 * 64 * PZ; f += 256) {
       const int p = f / (64 * PZ), rem = f - p * 64 * PZ, row = rem / PZ, u = rem - row * PZ;
       *reinterpret_cast<uint2*>(ximg + p * PLANE + row * XS + 2 * D + 8 * u) = uint2{0u, 0u};
     }
   }
-  __syncthreads();
-
-  f32x4 yacc[4][CT];
-#pragma unroll
-  for (int st = 0; st < 4; ++st)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) yacc[st][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the six kept terms, smallest first: (weight part, activation part)
   constexpr int TW[6] = {2, 0, 1, 1, 0, 0};
@@ -206,15 +256,37 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
 #pragma unroll
     for (int p = 0; p < 3; ++p) xf[s][p] = *reinterpret_cast<const uint4*>(ximg + xoff + p * PLANE + 16 * st * XS + 64 * s);
   };
+  float xr[RF > 0 ? RF : 1];  // fp32 remainder B fragments of the current subtile: X[row n][DB + 4 step + q]
+  int xro = 0;                // (opaque zero, like xoff: keeps these reads inside the loop)
+  auto read_xr = [&](int st) {
+#pragma unroll
+    for (int u = 0; u < RF; ++u) xr[u] = xrem[(16 * st + n) * XRS + 4 * u + q + xro];
+  };
+  unsigned long long st_b = 0, st_b_rt = 0, st_acc = 0, st_acc_rt = 0, st_first_b = 0, st_first_e = 0, st_epi = 0;
+  int st_tiles = 0;
+  constexpr int NSTG = 20;  // 4 pairs x 5 stages
+  for (;;) {  // tiles of this workgroup
+  const int m0 = tile * 64;
+  const int rows_valid = min(64, M - m0);
+  stage_store();  // (every wave left the previous tile's main loop -- the only reader of the image -- two barriers ago)
+  __syncthreads();
 #pragma unroll
   for (int s = 0; s < KS; ++s) read_x(0, s);
-  unsigned long long st_b = 0, st_b_rt = 0, st_e = 0, st_e_rt = 0;
-  if (stamp) st_b = __builtin_amdgcn_s_memtime(), st_b_rt = __builtin_amdgcn_s_memrealtime();
-  constexpr int NSTG = 20;  // 4 pairs x 5 stages
+  read_xr(0);
+  f32x4 yacc[4][CT];
+#pragma unroll
+  for (int st = 0; st < 4; ++st)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) yacc[st][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (stamp) {
+    st_b = __builtin_amdgcn_s_memtime(), st_b_rt = __builtin_amdgcn_s_memrealtime();
+    if (st_tiles == 0) st_first_b = st_b_rt;
+  }
   for (int i = 0; i < ncw; ++i) {
     // (opaque per iteration: otherwise all 12 KS X fragments are hoisted out of the loop into AGPRs and every MFMA
     // pays three v_accvgpr_read to get them back)
     asm volatile("" : "+v"(xoff));
+    asm volatile("" : "+v"(xro));
     f32x4 h[4][2];
     uint4 hf[4][3];
     const float bav[4] = {ba.x, ba.y, ba.z, ba.w}, bbv[4] = {bb.x, bb.y, bb.z, bb.w};
@@ -241,8 +313,25 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
     };
 #pragma unroll
     for (int st = 0; st < 4; ++st) {  // A(st) + B(st - 1)
-      constexpr int NM = 12 * KS;
+      constexpr int NM = 12 * KS + 2 * RF;
       h[st][0] = h[st][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (RF > 0) {  // the exact fp32 remainder steps first
+#pragma unroll
+        for (int u = 0; u < RF; ++u)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float a = u == 0 ? w1r[t].x : u == 1 ? w1r[t].y : u == 2 ? w1r[t].z : w1r[t].w;
+            h[st][t] = mfma16(a, xr[u], h[st][t]);
+            if (st > 0) {
+              const int mi = u * 2 + t;
+#pragma unroll
+              for (int v = mi * NSTG / NM; v < (mi + 1) * NSTG / NM; ++v) split_stage(st - 1, v);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        read_xr((st + 1) & 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
 #pragma unroll
@@ -251,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
           for (int t = 0; t < 2; ++t) {
             h[st][t] = mfma_bf16(w1[t][s][TW[k]], xf[s][TX[k]], h[st][t]);
             if (st > 0) {
-              const int mi = (s * 6 + k) * 2 + t;
+              const int mi = 2 * RF + (s * 6 + k) * 2 + t;
 #pragma unroll
               for (int u = mi * NSTG / NM; u < (mi + 1) * NSTG / NM; ++u) split_stage(st - 1, u);
               __builtin_amdgcn_sched_barrier(0);
@@ -261,8 +350,8 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // (unconditional, the last chunk reloads itself: a branch here would split the loop body into basic blocks)
-    load_w1_next(min(i + 1, ncw - 1));
+    // (unconditional: a branch here would split the loop body into basic blocks)
+    load_w1_next(i + 1 < ncw ? i + 1 : 0);  // the last chunk requests chunk 0: the next tile's first
     __builtin_amdgcn_sched_barrier(0);
     {
       constexpr int NM = 12 * CT;  // C0 C1 + B3
@@ -286,11 +375,17 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) yacc[st][ct] = mfma_bf16(w2[ct][TW[k]], hf[st][TX[k]], yacc[st][ct]);
     __builtin_amdgcn_sched_barrier(0);
-    load_w2(min(i + 1, ncw - 1));
+    load_w2(i + 1 < ncw ? i + 1 : 0);
     ba = ban, bb = bbn;
   }
 
-  if (stamp) st_e = __builtin_amdgcn_s_memtime(), st_e_rt = __builtin_amdgcn_s_memrealtime();
+  if (stamp) {
+    const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+    st_acc += __builtin_amdgcn_s_memtime() - st_b, st_acc_rt += rt - st_b_rt;
+    if (st_tiles == 0) st_first_e = rt;
+  }
+  const int tile_next = tile + (int)gridDim.x;
+  if (tile_next < ntiles) stage_load(tile_next);  // lands under the epilogue
   // ---- (w0 + w2) + (w1 + w3) through two LDS images, then residual + b2 + LN2 with 4 threads per row ----
   auto img_at = [&](int img, int st, int ct) { return red + ((size_t)img * 64 + 16 * st + n) * RS + 16 * ct + 4 * q; };
   if (wave < 2) {
@@ -358,10 +453,18 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
       }
     }
   }
+  if (stamp) {
+    if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
+    ++st_tiles;
+  }
+  if (tile_next >= ntiles) break;
+  tile = tile_next;
+  }  // tiles
   if (stamp && threadIdx.x == 0) {
     unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
-    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-    o[0] = st_e - st_b, o[1] = st_e_rt - st_b_rt, o[2] = st_entry, o[3] = st_b_rt, o[4] = st_e_rt, o[5] = now, o[6] = now, o[7] = 1;
+    o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
+    o[6] = __builtin_amdgcn_s_memrealtime();
+    o[7] = (unsigned long long)st_tiles | ((unsigned long long)__smid() << 32);
   }
 }
 
@@ -379,7 +482,8 @@ static hipError_t launch_split_d(const float* X, const LayerWeights& w, float* Y
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(M, 64)), dim3(256), SplitGeom<D>::lds, s, X, (const uint4*)w.w1s, w.b1,
+  const int ntiles = cdiv(M, 64);
+  hipLaunchKernelGGL(kern, dim3(ntiles < num_cus() ? ntiles : num_cus()), dim3(256), SplitGeom<D>::lds, s, X, (const uint4*)w.w1s, w.b1,
                      (const uint4*)w.w2s, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
   return hipGetLastError();
 }
