@@ -197,6 +197,11 @@ int ffd_tune(const char* key, int value) {
     g_ffn_split = value ? 1 : 0;
     return FFD_OK;
   }
+  if (!strcmp(key, "mid_path")) {  // 64-row FFN over F slices for mid-size M: 0 off, 1 heuristic, 2 / 4 / 8 forced
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return FFD_ERR_INVALID;
+    g_mid_path = value;
+    return FFD_OK;
+  }
   if (!strcmp(key, "small_wgs")) {  // most workgroups (row tiles x F splits) the small-M pair is used for
     if (value < 0) return FFD_ERR_INVALID;
     g_small_wgs = value;
@@ -691,7 +696,15 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
     } else {
       TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
-      if (split_ffn) TIMED(FFD_K_FFN, launch_ffn_ln_split(alt, w, cur, M, d, F, s));
+      const int nm = split_ffn ? 0 : mid_path_splits(M, d, F);
+      if (nm) {  // mid-size M: 64-row tiles x F slices, partial tiles + the reduce / LN2 launch
+        const size_t need = small_path_partial_floats(cdiv(M, 64) * 64, d, nm);
+        if (need > ctx->ffn_part_floats) {
+          if (int rc = dev_alloc(ctx, &ctx->ffn_part, need)) return rc;
+          ctx->ffn_part_floats = need;
+        }
+        TIMED(FFD_K_FFN, launch_ffn_mid(alt, w, ctx->ffn_part, cur, M, d, F, nm, s));
+      } else if (split_ffn) TIMED(FFD_K_FFN, launch_ffn_ln_split(alt, w, cur, M, d, F, s));
       else TIMED(FFD_K_FFN, launch_ffn_ln(alt, w, cur, M, d, F, s, nullptr, ctx->ffn_ctr));
     }
     if (mode == FULL) {
@@ -1230,6 +1243,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       else if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
         name = "k_oproj_ffn_split + k_ffn_reduce_ln", fl = 4.0 * M * d * F + 2.0 * M * d * d,
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
+      else if (tr && mid_path_splits((int)M, m.d_model, m.dim_feedforward))
+        name = "k_ffn_part", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       else if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       break;
     case FFD_K_ATTN:  // in-projection (Q only on a pure-cache step) + QK^T + PV; x in, attention output out

@@ -116,6 +116,10 @@ int small_path_splits(int M, int D, int F);
 size_t small_path_partial_floats(int M, int D, int NS);
 hipError_t launch_oproj_ffn_small(const float* attn, const float* xres, const LayerWeights& w, float* x1, float* P,
                                   float* Y, int M, int D, int F, int NS, hipStream_t s);
+// Mid-size M: the 64-row FFN main loop over F slices + the same reduce (ffd_small.hip); 0 = not this form
+int mid_path_splits(int M, int D, int F);
+hipError_t launch_ffn_mid(const float* x1, const LayerWeights& w, float* P, float* Y, int M, int D, int F, int NS, hipStream_t s);
+extern int g_mid_path;
 extern int g_small_path;
 extern int g_small_wgs;
 // Opt-in bf16x3-split FFN (ffd_tune "ffn_split"; ffd_ffn_split.hip)

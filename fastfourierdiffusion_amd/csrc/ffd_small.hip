@@ -219,6 +219,138 @@ __global__ __launch_bounds__(256) void k_oproj_ffn_split(const float* __restrict
   }
 }
 
+// Mid-size M (a few thousand to a few ten thousand rows; the reference's default sample_batch_size = 50 and its former
+// 200 are here): too many rows for 16-row tiles to stay efficient (every tile streams all weights), too few 64-row
+// tiles to fill the chip's 512 workgroup slots evenly (585 tiles = 1.14 rounds cost 2).  k_ffn_part is the 64-row
+// main loop of k_ffn_ln over hidden units [s F / NS, (s + 1) F / NS) only, grid (64-row tiles, NS): the work comes in
+// NS times finer units, and the partial Y tiles go through the same k_ffn_reduce_ln as the 16-row form (a 64-row tile
+// is written as four 16-row partial tiles).  Input is x1 (k_linear_res_ln stays a separate launch here).
+template <int D>
+__global__ __launch_bounds__(256, 2) void k_ffn_part(const float* __restrict__ X, const float* __restrict__ W1p,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2p,
+                                                     float* __restrict__ P, int M, int F, int NS) {
+  constexpr int S = lds_stride(D);
+  constexpr int KS = D / 4;
+  constexpr int G = dpack_groups(D);
+  constexpr int CT = cdiv(D, 16);
+  constexpr int MB = 4, R = 64;
+  constexpr int SP = ((D + 3) / 4) * 4 + 4;  // partial-sum row stride (16-byte aligned rows)
+  constexpr int D4 = D / 4;
+  __shared__ __align__(16) float xs[R * S];
+  __shared__ __align__(16) float red[2 * R * SP];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int m0 = tile * R;
+  const int rows_valid = min(R, M - m0);
+  const int n = lane & 15, q = lane >> 4;
+
+  // this wave's chunks (16 hidden units each) of the workgroup's F / NS slice
+  const int nchunk = F / (64 * NS);
+  const int fc0 = (split * 4 + wave) * nchunk;
+  const float4* W1q = reinterpret_cast<const float4*>(W1p) + (size_t)fc0 * G * 64 + lane;
+  const float4* W2q = reinterpret_cast<const float4*>(W2p) + (size_t)fc0 * CT * 64 + lane;
+  const float4* b1q = reinterpret_cast<const float4*>(b1 + 16 * fc0) + q;
+  float4 w1[G], w2[CT], bv;
+  auto load_w1 = [&](int c) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) w1[g] = W1q[((size_t)c * G + g) * 64];
+    bv = b1q[c * 4];
+  };
+  auto load_w2 = [&](int c) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) w2[ct] = W2q[((size_t)c * CT + ct) * 64];
+  };
+  load_w1(0);
+  load_w2(0);
+
+  // ---- stage the X tile (rows past M repeat the last valid row; their partials are never read) ----
+  for (int f = threadIdx.x; f < R * D4; f += 256) {
+    const int rr = f / D4, c4 = f - rr * D4;
+    const float4 v = *reinterpret_cast<const float4*>(X + (size_t)(m0 + min(rr, rows_valid - 1)) * D + 4 * c4);
+    float2* dst = reinterpret_cast<float2*>(&xs[rr * S + 4 * c4]);
+    dst[0] = float2{v.x, v.y}, dst[1] = float2{v.z, v.w};
+  }
+  __syncthreads();
+  float xf[MB][KS];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + n) * S + 4 * s + q];
+  f32x4 yacc[CT][MB];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the single-register-buffer software pipeline of k_ffn_ln: W1(c + 1) streams in under GEMM2(c), W2(c + 1) under
+  // GEMM1(c + 1); the sched_barriers pin the issue points
+  for (int ci = 0; ci < nchunk; ++ci) {
+    const int nx = (ci + 1 < nchunk) ? ci + 1 : ci;
+    f32x4 h[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) h[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 w4 = w1[s >> 2];
+      const float a = (s & 3) == 0 ? w4.x : (s & 3) == 1 ? w4.y : (s & 3) == 2 ? w4.z : w4.w;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) h[mb] = mfma16(a, xf[mb][s], h[mb]);
+    }
+    const float bvv[4] = {bv.x, bv.y, bv.z, bv.w};
+    __builtin_amdgcn_sched_barrier(0);
+    load_w1(nx);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[mb][r] = __builtin_amdgcn_fmed3f(h[mb][r] + bvv[r], 0.f, __builtin_inff());
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const float4 w4 = w2[ct];
+        const float a = r == 0 ? w4.x : r == 1 ? w4.y : r == 2 ? w4.z : w4.w;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(a, h[mb][r], yacc[ct][mb]);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    load_w2(nx);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- (w0 + w2) + (w1 + w3) through two LDS images, then the partial tile leaves as four 16-row tiles ----
+  auto img_at = [&](int img, int mb, int ct) { return red + ((size_t)img * R + 16 * mb + n) * SP + 16 * ct + 4 * q; };
+  if (wave < 2) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        if (16 * ct + 4 * q < D)
+          *reinterpret_cast<float4*>(img_at(wave, mb, ct)) = float4{yacc[ct][mb][0], yacc[ct][mb][1], yacc[ct][mb][2], yacc[ct][mb][3]};
+  }
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        if (16 * ct + 4 * q < D) {
+          float4* p = reinterpret_cast<float4*>(img_at(wave - 2, mb, ct));
+          const float4 a = *p;
+          *p = float4{a.x + yacc[ct][mb][0], a.y + yacc[ct][mb][1], a.z + yacc[ct][mb][2], a.w + yacc[ct][mb][3]};
+        }
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < R * D4; f += 256) {
+    const int rr = f / D4, c4 = f - rr * D4;
+    const float4 a = *reinterpret_cast<const float4*>(&red[rr * SP + 4 * c4]);
+    const float4 b = *reinterpret_cast<const float4*>(&red[(R + rr) * SP + 4 * c4]);
+    float* Pt = P + ((size_t)(4 * tile + (rr >> 4)) * NS + split) * 16 * D + (size_t)(rr & 15) * D;
+    *reinterpret_cast<float4*>(Pt + 4 * c4) = float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+  }
+}
+
 // y = LN2(x1 + b2 + sum_s P[tile][s]), partials added in split order; 16 threads per row
 template <int D>
 __global__ __launch_bounds__(256) void k_ffn_reduce_ln(const float* __restrict__ X1, const float* __restrict__ P,
@@ -303,6 +435,41 @@ int small_path_splits(int M, int D, int F) {
       if (cpw == 2 || cpw == 4 || cpw == 8 || cpw == 16) return ns;
     }
   return 0;
+}
+
+int g_mid_path = 1;  // ffd_tune "mid_path": 0 off, 1 heuristic, 2 / 4 / 8 force that many F slices where the form applies
+
+// F slices of the 64-row form for M rows, 0 = not this form (checked after small_path_splits).  Model fitted to
+// tools/sweep_mid.py: a CU retires a 64-row tile of k_ffn_ln every ~73 us whether it hosts one workgroup or two, so
+// the persistent kernel costs ceil(tiles / CUs) tile times; four F slices cost ceil(4 tiles / CUs) / 4 of them, times
+// 1.15 for what a slice pays per unit (X staging, first weight fetch, partial tile, no 4x4x1 remainder path, the
+// reduce launch).  Wins at 281 tiles (B = 96 at L = 187: 165 -> 127 us), 374 (167 -> 151), 585 (B = 200: 244 -> 228);
+// two slices were never better than four, eight only equal.
+int mid_path_splits(int M, int D, int F) {
+  if (!g_mid_path || D % 4 != 0 || D > 128) return 0;
+  if (g_mid_path > 1) return (F / 64) % g_mid_path == 0 ? g_mid_path : 0;
+  if ((F / 64) % 4 != 0) return 0;
+  const int tiles = cdiv(M, 64), cus = num_cus();
+  return 1.15 * cdiv(4 * tiles, cus) / 4.0 < (double)cdiv(tiles, cus) ? 4 : 0;
+}
+
+template <int D>
+static hipError_t launch_mid_t(const float* x1, const LayerWeights& w, float* P, float* Y, int M, int F, int NS, hipStream_t s) {
+  hipLaunchKernelGGL(k_ffn_part<D>, dim3(cdiv(M, 64), NS), dim3(256), 0, s, x1, w.w1p, w.b1, w.w2p, P, M, F, NS);
+  hipLaunchKernelGGL(k_ffn_reduce_ln<D>, dim3(cdiv(M, 16)), dim3(256), 0, s, x1, P, w.b2, w.n2w, w.n2b, Y, M, NS);
+  return hipGetLastError();
+}
+
+// y = LN2(x1 + FFN(x1)) with F cut into NS slices per 64-row tile; P: small_path_partial_floats(M rounded up to 64, D, NS)
+hipError_t launch_ffn_mid(const float* x1, const LayerWeights& w, float* P, float* Y, int M, int D, int F, int NS, hipStream_t s) {
+  if (M <= 0) return hipSuccess;
+  switch (D) {
+#define X(d) \
+  case d: return launch_mid_t<d>(x1, w, P, Y, M, F, NS, s);
+    FFD_D_LIST(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
 }
 
 size_t small_path_partial_floats(int M, int D, int NS) { return (size_t)cdiv(M, 16) * NS * 16 * D; }

@@ -293,6 +293,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
  *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most
  *                                              workgroups the split form is used for (0 = heuristic);
+ *   "mid_path" = 1 | 0 | 2 | 4 | 8            mid-size M: the 64-row FFN main loop over F slices + the reduce launch
+ *                                              (1 = where the round model says it pays, n = force n slices);
  *   "ffn_split" = 0 | 1                        OPT-IN, off by default: the FFN on the bf16 matrix cores, every fp32 operand cut
  *                                              into three bf16 parts and the six largest cross terms kept (fp32-equivalent to
  *                                              ~2e-7, passes the same goldens; NOT the reference's fp32 FMA arithmetic);

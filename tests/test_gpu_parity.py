@@ -1303,3 +1303,30 @@ def test_ffn_split_bf16x3_against_fp32_kernels(ffd, B):
         lib.ffd_tune(b"ffn_split", 0)
     assert torch.isfinite(a).all() and torch.equal(a, a2)
     assert rel_err(a.cpu(), ref.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,ns", [(50, 8), (100, 2), (200, 4), (200, 8), (257, 2)])
+def test_mid_batch_ffn_over_f_slices_matches_the_persistent_kernel(ffd, B, ns):
+    """Mid-size M (the reference's default sample_batch_size = 50, its former 200): the 64-row FFN main loop over NS
+    slices of the hidden dimension, partial tiles summed in slice order by k_ffn_reduce_ln (csrc/ffd_small.hip:
+    k_ffn_part).  Against k_linear_res_ln + k_ffn_ln on the same inputs: 2e-6 relative, deterministic; B = 257 ends in a
+    ragged 64-row tile (48 063 rows)."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 2024))).cuda()
+    try:
+        assert lib.ffd_tune(b"small_path", 0) == 0
+        assert lib.ffd_tune(b"mid_path", ns) == 0
+        a = m(batch_of(x, 0.6))
+        a2 = m(batch_of(x, 0.6))
+        assert lib.ffd_tune(b"mid_path", 0) == 0
+        b = m(batch_of(x, 0.6))
+    finally:
+        lib.ffd_tune(b"mid_path", 1)
+        lib.ffd_tune(b"small_path", 1)
+    assert torch.isfinite(a).all() and torch.equal(a, a2)
+    assert rel_err(a.cpu(), b.cpu()) < 2e-6

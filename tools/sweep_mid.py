@@ -25,12 +25,15 @@ def run(B):
         lib.ffd_kernel_timing_get(ctx.handle, cls, C.byref(ms), C.byref(n))
         out[cls] = ms.value * 1e3  # average per launch, us
     return out
-for B in (12, 16, 20, 24, 32, 48, 64, 96, 128, 192, 256, 384):
+for B in (16, 32, 50, 64, 96, 128, 200, 256, 320, 384, 512, 768):
     row = []
-    for name, tunes in (("mb1", {"small_path": 0, "ffn_mb": 1}), ("mb2", {"small_path": 0, "ffn_mb": 2}),
-                        ("mb4", {"small_path": 0, "ffn_mb": 4}),
-                        ("split640", {"small_path": 1, "small_wgs": 640, "ffn_mb": 0}),
-                        ("split2048", {"small_path": 1, "small_wgs": 2048, "ffn_mb": 0})):
+    for name, tunes in (("mb1", {"small_path": 0, "mid_path": 0, "ffn_mb": 1}), ("mb2", {"small_path": 0, "mid_path": 0, "ffn_mb": 2}),
+                        ("mb4", {"small_path": 0, "mid_path": 0, "ffn_mb": 4}),
+                        ("pair16", {"small_path": 1, "small_wgs": 0, "mid_path": 0, "ffn_mb": 0}),
+                        ("part2", {"small_path": 0, "mid_path": 2, "ffn_mb": 0}),
+                        ("part4", {"small_path": 0, "mid_path": 4, "ffn_mb": 0}),
+                        ("part8", {"small_path": 0, "mid_path": 8, "ffn_mb": 0}),
+                        ("auto", {"small_path": 1, "small_wgs": 0, "mid_path": 1, "ffn_mb": 0})):
         for k, v in tunes.items():
             lib.ffd_tune(k.encode(), v)
         t = run(B)
