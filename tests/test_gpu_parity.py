@@ -1330,3 +1330,34 @@ def test_mid_batch_ffn_over_f_slices_matches_the_persistent_kernel(ffd, B, ns):
         lib.ffd_tune(b"small_path", 1)
     assert torch.isfinite(a).all() and torch.equal(a, a2)
     assert rel_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(72, 12, 187), (60, 12, 50), (48, 12, 33), (64, 8, 100), (32, 4, 64), (16, 4, 20), (24, 8, 45),
+                                   (8, 4, 31)], ids=lambda s: f"d{s[0]}h{s[1]}L{s[2]}")
+def test_f_sliced_ffn_forms_on_every_d_model(ffd, shape):
+    """Every d_model instance of the F-sliced FFN kernels (k_ffn_part forced with 2 / 4 / 8 slices, and the 16-row pair)
+    against the oracle and against k_linear_res_ln + k_ffn_ln: their chunk loops carry weight fragments in registers
+    across iterations, the pattern hipcc 7.2 miscompiled once, so each instantiation is executed."""
+    from fastfourierdiffusion_amd import _native as N
+
+    d, H, L = shape
+    C, NL, B = 2, 2, 5
+    c = dict(kind="transformer", d=d, H=H, NL=NL, L=L, C=C, sde="vp", sde_kwargs=cases.VP, fourier=True, wseed=700 + d + L)
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 9100 + d)))
+    t = torch.full((B,), 0.35, dtype=torch.float32)
+    ref = O.score_forward(x, t, sd, NL, H)
+    lib = N.lib()
+    outs = {}
+    try:
+        for name, (sp, mp) in {"large": (0, 0), "pair16": (1, 0), "part2": (0, 2), "part4": (0, 4), "part8": (0, 8)}.items():
+            assert lib.ffd_tune(b"small_path", sp) == 0 and lib.ffd_tune(b"mid_path", mp) == 0
+            outs[name] = m(batch_of(x.cuda(), 0.35)).cpu()
+    finally:
+        lib.ffd_tune(b"small_path", 1)
+        lib.ffd_tune(b"mid_path", 1)
+    for name, o in outs.items():
+        assert rel_err(o, ref) < TOL_SCORE, name
+        assert rel_err(o, outs["large"]) < 2e-6, name
