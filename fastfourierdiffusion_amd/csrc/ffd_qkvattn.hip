@@ -89,6 +89,25 @@ hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, i
   return hipGetLastError();
 }
 
+// Squared norms of the (scaled) q rows and of the k rows, maximum per 32-token tile: nrm[0 .. KT) keys, nrm[KT .. 2 KT)
+// queries.  |q . k| <= |q| |k| bounds every score of a (q-tile, key tile) pair; while that bound is within the
+// threshold T the online softmax needs no running maximum (its reference stays 0), and the block skips the max
+// reduction, the cross-half exchange and the refresh test -- about a tenth of its vector instructions.
+template <int HD>
+__device__ __forceinline__ void tile_norms(const float* kts, const float* qts, float* nrm, int Lp, int KT, int tid, int nthreads) {
+  for (int j = tid; j < Lp; j += nthreads) {  // (tid and nthreads are multiples of 32 apart: a 32-lane group = one tile)
+    float k2 = 0.f, q2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < HD; ++e) {
+      const float kv = kts[e * Lp + j], qv = qts[e * Lp + j];
+      k2 = fmaf(kv, kv, k2), q2 = fmaf(qv, qv, q2);
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o)), q2 = fmaxf(q2, __shfl_xor(q2, o));
+    if ((j & 31) == 0) nrm[j >> 5] = k2, nrm[KT + (j >> 5)] = q2;
+  }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------
 //
 // SPLIT (small batches, e.g. the benchmark_cache.py harness at batch 1: B*H workgroups would leave most of the chip
@@ -269,6 +288,8 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
   }
   __syncthreads();
+  float* nrm = lds + (size_t)Lp * (8 + 4 * KST) + (SPLIT ? 4 * 32 * (2 + 2 * HP) : 0);  // [2][KT], see tile_norms
+  tile_norms<HD>(kts, qts, nrm, Lp, KT, threadIdx.x, blockDim.x);
   // MIXED: batch element 0 publishes its recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
   if (kt_out != nullptr && b == 0 && qs == 0) {
     for (int idx = threadIdx.x; idx < n_own * HD; idx += blockDim.x) {
@@ -278,6 +299,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
   }
 
+  __syncthreads();  // the tile norms
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -303,8 +325,11 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     if (q_first >= QT) t_hi = t_lo;  // ragged last workgroup: an empty piece
   }
   for (int qt0 = q_first; qt0 < q_end; qt0 += q_step) {
-    float qf[QG][KSX], mref[QG];
+    float qf[QG][KSX], mref[QG], qn2[QG];
     bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
+    bool acc_empty[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) acc_empty[g] = true;
     f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -315,6 +340,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;  // dim HD starts at -m_ref = 0
       }
       mref[g] = 0.f;
+      qn2[g] = nrm[KT + qtile];
       lsum[g] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
@@ -322,6 +348,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll 1
     for (int t = t_lo; t < t_hi; ++t) {
       float kf[KSX];
+      const float kn2 = nrm[t];
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
@@ -354,6 +381,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
+        // every score of this block is within +-sqrt(qn2 kn2): while that stays within T and no lane of the wave uses a
+        // reference, nothing below can trigger (wave-uniform: the norms are the same in every lane)
+        const bool bounded = !ref_on && qn2[g] * kn2 <= T * T;
+        if (__builtin_amdgcn_ballot_w64(!bounded) != 0) {
         float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
@@ -361,12 +392,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
         // m_ref starts at 0 and usually stays there: |scores| <= 64 (log2 domain) neither overflow nor lose the row
         // to underflow, and the factor 2^-m_ref cancels in the normalisation whatever it is.
-        const bool refresh = (t == t_lo) ? (fabsf(bmx) > T) : (bmx > T);
+        const bool first = acc_empty[g];  // nothing accumulated yet: this is the row's first key tile
+        const bool refresh = first ? (fabsf(bmx) > T) : (bmx > T);
         if (__builtin_amdgcn_ballot_w64(refresh) != 0) ref_on = true;
         if (refresh) {
           const float delta = bmx;
           mref[g] += delta;
-          if (t != t_lo) {
+          if (!first) {
             const float corr = __builtin_amdgcn_exp2f(-delta);
             lsum[g] *= corr;
 #pragma unroll
@@ -376,6 +408,8 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
           for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
           if (xlane) qf[g][SX] = -mref[g];
         }
+        }
+        acc_empty[g] = false;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float p0 = __builtin_amdgcn_exp2f(sc[g][r]);
@@ -644,6 +678,8 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     }
   }
   __syncthreads();
+  float* nrm = lds + (size_t)HPW * RS + (size_t)NCT * S4 * 256 + (size_t)hh * 2 * KT;  // this head's [2][KT], see tile_norms
+  tile_norms<HD>(kts, qts, nrm, Lp, KT, gw * 64 + lane, 128);
   if (kt_out != nullptr && b == 0) {  // MIXED: batch element 0 publishes its recomputed rows
     const int tid2 = gw * 64 + lane;
     for (int idx = tid2; idx < n_own * HD; idx += 128) {
@@ -653,6 +689,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     }
   }
 
+  __syncthreads();  // the tile norms
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -669,8 +706,11 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   };
   const int QT = KT;
   for (int qt0 = gw * QG; qt0 < QT; qt0 += 2 * QG) {
-    float qf[QG][KSX], mref[QG];
+    float qf[QG][KSX], mref[QG], qn2[QG];
     bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
+    bool acc_empty[QG];
+#pragma unroll
+    for (int g = 0; g < QG; ++g) acc_empty[g] = true;
     f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
@@ -681,6 +721,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;
       }
       mref[g] = 0.f;
+      qn2[g] = nrm[KT + qtile];
       lsum[g] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
@@ -688,6 +729,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
 #pragma unroll 1
     for (int t = 0; t < KT; ++t) {
       float kf[KSX];
+      const float kn2 = nrm[t];
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
@@ -720,6 +762,10 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
+        // every score of this block is within +-sqrt(qn2 kn2): while that stays within T and no lane of the wave uses a
+        // reference, nothing below can trigger (wave-uniform: the norms are the same in every lane)
+        const bool bounded = !ref_on && qn2[g] * kn2 <= T * T;
+        if (__builtin_amdgcn_ballot_w64(!bounded) != 0) {
         float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
@@ -727,12 +773,13 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         const float bmx = fmaxf(bm, __shfl_xor(bm, 32));
         // m_ref starts at 0 and usually stays there: |scores| <= 64 (log2 domain) neither overflow nor lose the row
         // to underflow, and the factor 2^-m_ref cancels in the normalisation whatever it is.
-        const bool refresh = (t == 0) ? (fabsf(bmx) > T) : (bmx > T);
+        const bool first = acc_empty[g];  // nothing accumulated yet: this is the row's first key tile
+        const bool refresh = first ? (fabsf(bmx) > T) : (bmx > T);
         if (__builtin_amdgcn_ballot_w64(refresh) != 0) ref_on = true;
         if (refresh) {
           const float delta = bmx;
           mref[g] += delta;
-          if (t != 0) {
+          if (!first) {
             const float corr = __builtin_amdgcn_exp2f(-delta);
             lsum[g] *= corr;
 #pragma unroll
@@ -742,6 +789,8 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
           for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
           if (xlane) qf[g][SX] = -mref[g];
         }
+        }
+        acc_empty[g] = false;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           const float p0 = __builtin_amdgcn_exp2f(sc[g][r]);
@@ -797,7 +846,7 @@ static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt,
   constexpr int KST = (HD + 1) / 2;
   constexpr int S4 = (D + 15) / 16;
   const int KT = (L + 31) / 32;
-  const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256) * sizeof(float);
+  const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2 * KT) * sizeof(float);
   auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
   if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
   hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
@@ -825,7 +874,7 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
                            float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
   constexpr int KST = (HD + 1) / 2;
   const int KT = (L + 31) / 32;
-  const size_t lds = (size_t)KT * 32 * (8 + 4 * KST) * sizeof(float);
+  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)2 * KT) * sizeof(float);
   int nwaves = cdiv(KT, QG);
   if (nwaves > 4) nwaves = 4;
   if (cdiv(2 * KT, nwaves) > 8) return hipErrorInvalidValue;  // the projection loop is unrolled for <= 8 token tiles per wave
@@ -842,7 +891,7 @@ static hipError_t launch_split_t(const float* x, const float* awp, const float* 
   const int KT = (L + 31) / 32;
   if (cdiv(2 * KT, 4) > 8 || (kspl != 1 && kspl != 2 && kspl != 4)) return hipErrorInvalidValue;
   const int qsplit = cdiv(KT, 4 / kspl);
-  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP)) * sizeof(float);
+  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP) + (size_t)2 * KT) * sizeof(float);
   hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
                      vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl);
   return hipGetLastError();

@@ -1,0 +1,24 @@
+"""In-situ HIP-event time of the attention class for a workload / batch: tools/probes/attn_time.py ecg 512"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch, bench
+from fastfourierdiffusion_amd import _native as N
+wl = sys.argv[1] if len(sys.argv) > 1 else "ecg"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+dev = torch.device("cuda", 0)
+model, sch, _ = bench.build_model(dev, wl)
+ctx = model._ctx(); lib = ctx.lib
+L, Cn, NL = model.max_len, model.n_channels, model.num_layers
+sch.set_timesteps(50)
+ts_c = (C.c_float * 50)(*sch.timesteps.tolist())
+x = torch.randn(B, L, Cn, device=dev)
+s = N.current_stream_ptr(dev)
+nst = 4
+for rep in range(3):
+    N.check(lib.ffd_sample_batch(ctx.handle, x.data_ptr(), B, ts_c, 50, float(sch.step_size), 0, 2, 1, 0, None, 0, 0, s), ctx.handle, "warm")
+    N.check(lib.ffd_kernel_timing_begin(ctx.handle, 0xFF, nst * (3 * NL + 3)), ctx.handle, "begin")
+    N.check(lib.ffd_sample_batch(ctx.handle, x.data_ptr(), B, ts_c, 50, float(sch.step_size), 0, nst, 1, 0, None, 0, 0, s), ctx.handle, "sample")
+    N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "end")
+    ms, n = C.c_float(), C.c_int()
+    lib.ffd_kernel_timing_get(ctx.handle, N.K_ATTN, C.byref(ms), C.byref(n))
+    print(f"{wl} B={B}: attention {ms.value*1e3:.1f} us per launch ({n.value} launches)", flush=True)
