@@ -177,12 +177,14 @@ __global__ __launch_bounds__(256) void k_linear_hm(const float* __restrict__ X, 
 }
 
 // out-proj + residual + LayerNorm1.  HBM-bound: 12 d bytes per row (attention output and residual in, LN1 output
-// out) against 2 d^2 FLOP.  Persistent over 64-row tiles (grid = the workgroups the chip holds, two per CU): the
-// weight fragments stay in registers for all tiles, the NEXT tile's X and R rows stream into the second half of a
-// double-buffered LDS image by LDS-DMA (global_load_lds_dwordx4, no VGPRs) while the current tile is computed, and the
-// finished rows leave through the wave's own rows of the X image as whole 1 KiB runs (the accumulator layout would
-// store sixteen 64-byte pieces per instruction).  One workgroup per tile took 28 us on the ECG shape: two dependent
-// HBM round trips per workgroup and 1.46 rounds of workgroups.
+// out) against 2 d^2 FLOP.  Persistent (grid = the workgroups the chip holds, two per CU), and every WAVE is its own
+// stream of 16-row tiles: the weight fragments stay in registers for all tiles, the NEXT tile's X and R rows stream
+// into the second half of the wave's double-buffered LDS images by LDS-DMA (global_load_lds_dwordx4, no VGPRs) while
+// the current tile is computed, and the finished rows leave through the X image as whole 1 KiB runs (the accumulator
+// layout would store sixteen 64-byte pieces per instruction).  A wave touches only its own images, so there is no
+// workgroup barrier anywhere: the four waves of a workgroup drift apart and a stall of one (an image that has not
+// landed) does not hold the others.  (The 64-row workgroup tile with a barrier per tile took 25.3 us on the ECG
+// shape, one workgroup per tile 28 us.)
 template <int D>
 __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restrict__ X, const float* __restrict__ Wp,
                                                           const float* __restrict__ bias, const float* __restrict__ R,
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
   constexpr int CT = cdiv(D, 16);
   constexpr int SX = ((D + 3) / 4) * 4 + 4;  // image row stride: whole float4 slots (lane-linear LDS-DMA image), one pad slot
   constexpr int S4 = SX / 4;
-  constexpr int TR = 64;                     // rows per tile
+  constexpr int TR = 16;                     // rows per tile (one wave)
   constexpr int NPC = (TR * S4 + 63) / 64;   // 1 KiB DMA pieces per image
-  __shared__ __align__(16) float img[2][2][TR * SX];  // [buffer][X | R][row][SX]
+  __shared__ __align__(16) float imgs[4][2][2][TR * SX];  // [wave][buffer][X | R][row][SX] (the last DMA piece is partial: lanes past the image do not write)
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
   const int lane = threadIdx.x & 63;
@@ -223,29 +225,30 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
   auto issue_dma = [&](int t, int b) {  // rows past M repeat the last valid row (never stored)
     const int rows_valid = min(TR, M - t * TR);
     const size_t base = (size_t)t * TR * D;
-    for (int pc = wave; pc < NPC; pc += 4) {
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) {
       const int p = pc * 64 + lane;
       const int r = p / S4, c4 = p - r * S4;
       const size_t off = base + (size_t)min(r, rows_valid - 1) * D + 4 * min(c4, D / 4 - 1);
       if (p < TR * S4) {
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(X + off), (lds_ptr_t)(&img[b][0][pc * 256]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(R + off), (lds_ptr_t)(&img[b][1][pc * 256]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(X + off), (lds_ptr_t)(&imgs[wave][b][0][pc * 256]), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(R + off), (lds_ptr_t)(&imgs[wave][b][1][pc * 256]), 16, 0, 0);
       }
     }
   };
 
   int buf = 0;
-  int tile = blockIdx.x;
+  const int tstep = (int)gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
   if (tile < ntiles) issue_dma(tile, 0);
-  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+  for (; tile < ntiles; tile += tstep, buf ^= 1) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's images have landed (and the previous tile's stores left)
-    __syncthreads();
-    float* xs = img[buf][0];
-    const float* rs = img[buf][1];
+    float* xs = imgs[wave][buf][0];
+    const float* rs = imgs[wave][buf][1];
     float xf[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) xf[s] = xs[(16 * wave + (lane & 15)) * SX + 4 * s + (lane >> 4)];
-    if (tile + (int)gridDim.x < ntiles) issue_dma(tile + gridDim.x, buf ^ 1);
+    for (int s = 0; s < KS; ++s) xf[s] = xs[(lane & 15) * SX + 4 * s + (lane >> 4)];
+    if (tile + tstep < ntiles) issue_dma(tile + tstep, buf ^ 1);
 
     f32x4 acc[CT];
 #pragma unroll
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
       }
     }
     // epilogue: lane holds row (lane & 15) of the wave's 16, columns n = 16 ct + 4 (lane >> 4) + r
-    const int lr = 16 * wave + (lane & 15);
+    const int lr = lane & 15;
     const float* rrow = rs + lr * SX;
     float v[CT][4];
     float sum = 0.f;
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
     ss += __shfl_xor(ss, 16);
     ss += __shfl_xor(ss, 32);
     const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
-    // finished rows -> the wave's own rows of the X image (its fragments are in registers; no other wave reads them)
+    // finished rows -> the X image (its fragments are in registers)
     float* orow = xs + lr * SX;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -308,12 +311,12 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
       }
     }
     // ... and out as contiguous runs: the wave's 16 rows are 16 * D consecutive floats of Y
-    const int row0 = tile * TR + 16 * wave;
+    const int row0 = tile * TR;
     float4* y4 = reinterpret_cast<float4*>(Y + (size_t)row0 * D);
-    const int nvalid = min(16, M - row0);  // (<= 0: nothing to store)
+    const int nvalid = min(16, M - row0);
     for (int f = lane; f < 16 * (D / 4); f += 64) {
       const int r = f / (D / 4), c4 = f - r * (D / 4);
-      if (r < nvalid) y4[f] = *reinterpret_cast<const float4*>(xs + (16 * wave + r) * SX + 4 * c4);
+      if (r < nvalid) y4[f] = *reinterpret_cast<const float4*>(xs + r * SX + 4 * c4);
     }
   }
 }
@@ -455,8 +458,8 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
     resident = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
                 prop.multiProcessorCount > 0) ? 2 * prop.multiProcessorCount : 512;
   }
-  const int ntiles = cdiv(M, 64);
-  dim3 grid(ntiles < resident ? ntiles : resident), block(256);
+  const int nwg = cdiv(cdiv(M, 16), 4);  // four 16-row wave tiles per workgroup
+  dim3 grid(nwg < resident ? nwg : resident), block(256);
   switch (D) {
 #define X(d) \
     case d: hipLaunchKernelGGL(k_linear_res_ln<d>, grid, block, 0, s, X, Wp, bias, R, g, beta, Y, M); break;

@@ -1,4 +1,4 @@
-"""In-situ HIP-event time of the attention class for a workload / batch: tools/probes/attn_time.py ecg 512"""
+"""In-situ HIP-event time per kernel class for a workload / batch: tools/probes/attn_time.py ecg 512"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
@@ -19,6 +19,9 @@ for rep in range(3):
     N.check(lib.ffd_kernel_timing_begin(ctx.handle, 0xFF, nst * (3 * NL + 3)), ctx.handle, "begin")
     N.check(lib.ffd_sample_batch(ctx.handle, x.data_ptr(), B, ts_c, 50, float(sch.step_size), 0, nst, 1, 0, None, 0, 0, s), ctx.handle, "sample")
     N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "end")
-    ms, n = C.c_float(), C.c_int()
-    lib.ffd_kernel_timing_get(ctx.handle, N.K_ATTN, C.byref(ms), C.byref(n))
-    print(f"{wl} B={B}: attention {ms.value*1e3:.1f} us per launch ({n.value} launches)", flush=True)
+    row = []
+    for name, cls in (("ffn", N.K_FFN), ("attention", N.K_ATTN), ("out-proj", N.K_OUTPROJ), ("embed", N.K_EMBED), ("tail", N.K_SDE)):
+        ms, n = C.c_float(), C.c_int()
+        lib.ffd_kernel_timing_get(ctx.handle, cls, C.byref(ms), C.byref(n))
+        row.append(f"{name} {ms.value*1e3:.1f}")
+    print(f"{wl} B={B}: us per launch (in-situ HIP events): " + "  ".join(row), flush=True)
