@@ -188,6 +188,10 @@ int ffd_tune(const char* key, int value) {
     g_attn_small = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "embed_ldsx")) {  // embedding kernel: the wave's x rows through LDS (1) or per-lane loads (0)
+    g_embed_ldsx = value ? 1 : 0;
+    return FFD_OK;
+  }
   if (!strcmp(key, "embed_threads")) {
     if (value < 256) return FFD_ERR_INVALID;
     g_embed_threads = value;

@@ -146,19 +146,35 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 // threads of a row share them through L1), 4 C FMAs and one float4 store -- consecutive threads are consecutive
 // float4 of consecutive rows, every wave writes one contiguous 1 KiB run.  No LDS, no table reads, no integer
 // division in the loop; four samples per iteration keep four rows of loads in flight.
-template <bool XVEC>
+//
+// LDSX: the D/4 threads of a row all need the same C floats of x.  As per-lane loads that is two 64-lane float4
+// load instructions per stored KiB -- twice the address-path work of the store itself, and the kernel ran at 2.9 TB/s
+// where its stores alone reach 6.1 (tools/probes/embed_sweep.py with the loads removed).  Instead the wave fetches the
+// (<= 64) contiguous floats of x its 64 lanes' rows need with ONE dword load, parks them in LDS and every lane reads
+// its row from there.  Slices are padded to whole waves so that the cooperating lanes share (slice, first row).
+template <bool XVEC, bool LDSX>
 __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, const float* __restrict__ We,
                                                    const float* __restrict__ be, const float* __restrict__ pos,
                                                    const float* __restrict__ temb, int temb_stride,
                                                    float* __restrict__ h, int B, int L, int C, int D, int nslices) {
+  __shared__ __align__(16) float xsh[LDSX ? 4 * 8 * 64 : 4];  // [wave][2 groups x 4 samples][float of the wave's x rows]
   const unsigned D4 = (unsigned)D >> 2;
   const unsigned LJ = (unsigned)L * D4;
+  const unsigned LJP = LDSX ? (LJ + 63u) & ~63u : LJ;  // threads per slice
   const unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned slice = g / LJ;
+  const unsigned slice = g / LJP;
   if (slice >= (unsigned)nslices) return;
-  const unsigned lj = g - slice * LJ;
+  const unsigned ljr = g - slice * LJP;
+  const bool active = ljr < LJ;                    // (LDSX: the pad lanes of a slice's last wave help load, never store)
+  const unsigned lj = active ? ljr : LJ - 1;
   const unsigned l = lj / D4;
   const int j = (int)(lj - l * D4) << 2;
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned r0 = (ljr - lane) / D4;           // first row of this wave
+  const unsigned rl = min(ljr - lane + 63u, LJ - 1) / D4;
+  const unsigned nf = (rl - r0 + 1) * (unsigned)C;  // floats of x the wave needs per sample (<= 64, launcher)
+  const unsigned rel = (l - r0) * (unsigned)C;
+  float* xw = xsh + (LDSX ? (threadIdx.x >> 6) * 512 : 0);
   float4 w[8];
   if (XVEC) {  // C = 4 or 8: the four weight rows j .. j+3 as float4 loads (8 instead of 32 per thread)
     float wr[4][8];
@@ -180,8 +196,11 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
   const float4 bias = *reinterpret_cast<const float4*>(be + j);
   const float4 p = pos ? *reinterpret_cast<const float4*>(pos + (size_t)l * D + j) : float4{0.f, 0.f, 0.f, 0.f};
   const float4 t0 = *reinterpret_cast<const float4*>(temb + j);  // the shared time embedding (temb_stride == 0)
-  auto load_x = [&](int b, float (&xv)[8]) {
-    const float* x = X + ((size_t)b * L + l) * C;
+  auto fetch_x = [&](int b, int u) {  // LDSX: the wave's x floats of sample b -> LDS slot u
+    if (lane < nf) xw[u * 64 + lane] = X[((size_t)b * L + r0) * C + lane];
+  };
+  auto load_x = [&](int b, int u, float (&xv)[8]) {
+    const float* x = LDSX ? xw + u * 64 + rel : X + ((size_t)b * L + l) * C;
     if (XVEC) {
       const float4 a = *reinterpret_cast<const float4*>(x);
       xv[0] = a.x, xv[1] = a.y, xv[2] = a.z, xv[3] = a.w;
@@ -201,19 +220,38 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
       if (c < C) v.x = fmaf(xv[c], w[c].x, v.x), v.y = fmaf(xv[c], w[c].y, v.y), v.z = fmaf(xv[c], w[c].z, v.z), v.w = fmaf(xv[c], w[c].w, v.w);
     if (pos) v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
     const float4 t = temb_stride ? *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j) : t0;
-    *reinterpret_cast<float4*>(h + ((size_t)b * L + l) * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
+    if (active) *reinterpret_cast<float4*>(h + ((size_t)b * L + l) * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
   };
   int b = (int)slice;
+  int grp = 0;  // LDSX: which half of the wave's LDS slots holds the current group of four samples
+  if (LDSX && b + 3 * nslices < B) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch_x(b + u * nslices, u);
+  }
   for (; b + 3 * nslices < B; b += 4 * nslices) {
     float xa[4][8];
+    if (LDSX) {  // the next group's x is requested before this group is consumed (the loop is latency-bound otherwise)
+      if (b + 7 * nslices < B) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) load_x(b + u * nslices, xa[u]);
+        for (int u = 0; u < 4; ++u) fetch_x(b + (4 + u) * nslices, 4 * (grp ^ 1) + u);
+      }
+      __builtin_amdgcn_wave_barrier();  // (one wave, in-order LDS: only the compiler must keep the order)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) load_x(b + u * nslices, 4 * grp + u, xa[u]);
+    if (LDSX) __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int u = 0; u < 4; ++u) emit(b + u * nslices, xa[u]);
+    grp ^= 1;
   }
   for (; b < B; b += nslices) {
     float xa[8];
-    load_x(b, xa);
+    if (LDSX) {
+      fetch_x(b, 0);
+      __builtin_amdgcn_wave_barrier();
+    }
+    load_x(b, 0, xa);
+    if (LDSX) __builtin_amdgcn_wave_barrier();
     emit(b, xa);
   }
 }
@@ -250,6 +288,7 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
   }
 }
 
+int g_embed_ldsx = 1;  // ffd_tune "embed_ldsx": 0 = every lane loads its row's x itself
 int g_embed_threads = 262144;  // ffd_tune "embed_threads": threads the embed grid aims at (tools/probes/embed_sweep.py: 114 us at 256 k, 118 at 512 k, 137 at 128 k on the config-5 shape)
 
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
@@ -258,14 +297,24 @@ hipError_t launch_embed(const float* X, const float* We, const float* be, const 
   const unsigned total4 = (unsigned)((size_t)M * D / 4);
   if (C <= 8 && D % 4 == 0) {
     // one thread per (l, float4 column) and batch slice: as many slices as give ~512 k threads
-    const unsigned LJ = (unsigned)L * (unsigned)(D / 4);
-    int nslices = (int)((unsigned)g_embed_threads / LJ);
+    const unsigned D4 = (unsigned)(D / 4);
+    const unsigned LJ = (unsigned)L * D4;
+    // x through LDS when the rows of 64 consecutive lanes (64 / D4, + 2 for a wave that starts and ends mid-row)
+    // need at most 64 floats of x
+    const bool ldsx = g_embed_ldsx && (64u / D4 + 2u) * (unsigned)C <= 64u;
+    const unsigned LJP = ldsx ? (LJ + 63u) & ~63u : LJ;
+    int nslices = (int)((unsigned)g_embed_threads / LJP);
     if (nslices < 1) nslices = 1;
     if (nslices > B) nslices = B;
-    const unsigned blocks = (unsigned)(((size_t)nslices * LJ + 255) / 256);
+    const unsigned blocks = (unsigned)(((size_t)nslices * LJP + 255) / 256);
     const bool xvec = (C == 4 || C == 8) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(We)) & 15) == 0;
-    if (xvec) hipLaunchKernelGGL(k_embed_reg<true>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices);
-    else hipLaunchKernelGGL(k_embed_reg<false>, dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices);
+#define FFD_EMBED(xv, lx) \
+  hipLaunchKernelGGL((k_embed_reg<xv, lx>), dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices)
+    if (xvec && ldsx) FFD_EMBED(true, true);
+    else if (xvec) FFD_EMBED(true, false);
+    else if (ldsx) FFD_EMBED(false, true);
+    else FFD_EMBED(false, false);
+#undef FFD_EMBED
     return hipGetLastError();
   }
   unsigned blocks = (total4 + 255) / 256;

@@ -125,6 +125,7 @@ extern int g_small_wgs;
 // Opt-in bf16x3-split FFN (ffd_tune "ffn_split"; ffd_ffn_split.hip)
 extern int g_ffn_split;
 extern int g_embed_threads;
+extern int g_embed_ldsx;
 bool ffn_split_supported(int D, int F);
 size_t w1split_bytes(int D, int F);
 size_t w2split_bytes(int D, int F);

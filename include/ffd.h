@@ -299,7 +299,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *                                              into three bf16 parts and the six largest cross terms kept (fp32-equivalent to
  *                                              ~2e-7, passes the same goldens; NOT the reference's fp32 FMA arithmetic);
  *                                              needs d_model <= 96, dim_feedforward % 128 == 0 (ffd_ffn_split.hip);
- *   "embed_threads" = n                        threads the embedding kernel's grid aims at (default 262144);
+ *   "embed_threads" = n                        threads the embedding kernel's grid aims at (default 262144); "embed_ldsx" = 1 | 0:
+ *                                              a wave's shared x rows through LDS or per-lane loads;
  *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
  *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
  *   "ffn_prio" = 1 | 0                         fused FFN: raised wave priority outside the main loop;
