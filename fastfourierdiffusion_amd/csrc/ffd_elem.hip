@@ -301,7 +301,8 @@ hipError_t launch_embed(const float* X, const float* We, const float* be, const 
     const unsigned LJ = (unsigned)L * D4;
     // x through LDS when the rows of 64 consecutive lanes (64 / D4, + 2 for a wave that starts and ends mid-row)
     // need at most 64 floats of x
-    const bool ldsx = g_embed_ldsx && (64u / D4 + 2u) * (unsigned)C <= 64u;
+    // (only where it replaces float4 loads, C = 4 or 8: with one float per row the detour costs more than it saves)
+    const bool ldsx = g_embed_ldsx && (C == 4 || C == 8) && (64u / D4 + 2u) * (unsigned)C <= 64u;
     const unsigned LJP = ldsx ? (LJ + 63u) & ~63u : LJ;
     int nslices = (int)((unsigned)g_embed_threads / LJP);
     if (nslices < 1) nslices = 1;
