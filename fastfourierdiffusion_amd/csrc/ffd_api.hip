@@ -216,7 +216,7 @@ int ffd_tune(const char* key, int value) {
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_prio")) {  // raised wave priority outside the FFN main loop
-    g_ffn_prio = value == 2 ? 2 : value ? 1 : 0;  // 2: alternate the priority every four chunks inside the main loop (experiment)
+    g_ffn_prio = (value == 2 || value == 3) ? value : value ? 1 : 0;  // 2: alternate the priority every four chunks inside the main loop (experiment)
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_dynamic")) {  // persistent FFN: tiles from a device counter (1) or static round robin (0)

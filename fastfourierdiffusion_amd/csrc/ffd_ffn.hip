@@ -79,7 +79,9 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   const int ntiles = (M + R - 1) / R;
   const bool prio_epilogue = (stagger & 0x40000000) != 0;  // (launcher flags folded into the stagger argument)
   const bool prio_alternate = (stagger & 0x20000000) != 0;
-  stagger &= 0x1FFFFFFF;
+  const bool prio_opposed = (stagger & 0x10000000) != 0;  // ... and the two wave slots of a SIMD in opposite phase
+  stagger &= 0x0FFFFFFF;
+  const int prio_phase = prio_opposed ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u) : 0;  // HW_ID wave slot
 
   // a tile's X rows -> image `b`, asynchronously (rows past M repeat the last valid row; they are never stored)
   auto issue_dma = [&](int t, int b) {
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
       // (experiment, ffd_tune "ffn_prio" = 2: the wave alternates between two priorities every four chunks, so that
       //  neither of the two workgroups of a CU owns the issue slots for a whole launch)
       if (prio_alternate && (ci & 3) == 0) {
-        if (ci & 4) __builtin_amdgcn_s_setprio(1);
+        if (((ci >> 2) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
         else __builtin_amdgcn_s_setprio(0);
       }
       const int nx = (ci + 1 < nchunk) ? ci + 1 : 0;  // the last prefetch wraps to chunk 0 = the next tile's first chunk
@@ -490,8 +492,8 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   // ECG step is fastest without it (5.89 ms against 5.92 at 792, 5.98 at 2900: tools/probes/step_ab.py).  The per-CU
   // timeline (tools/ffn_timeline.py) shows why de-phasing cannot help: of the two workgroups of a CU one gets the
   // issue slots (3 tiles by 365 us), the other trails (440 us) -- 73 us per tile shared, 71 alone.
-  const int stagger = (g_ffn_stagger >= 0 ? (g_ffn_stagger & 0x1FFFFFFF) : 0) | (g_ffn_prio == 1 ? 0x40000000 : 0) |
-                      (g_ffn_prio == 2 ? 0x20000000 : 0);
+  const int stagger = (g_ffn_stagger >= 0 ? (g_ffn_stagger & 0x0FFFFFFF) : 0) | (g_ffn_prio == 1 ? 0x40000000 : 0) |
+                      (g_ffn_prio >= 2 ? 0x20000000 : 0) | (g_ffn_prio == 3 ? 0x10000000 : 0);
   dim3 block(256);
   // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
   const int resident = num_cus() * (mb == 4 ? 2 : 1) * (g_ffn_persist > 0 ? g_ffn_persist : 1);

@@ -15,6 +15,8 @@ model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx()
 s = N.current_stream_ptr(dev)
 assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0 and ctx.lib.ffd_tune(b"ffn_dynamic", dynamic) == 0
+if os.environ.get("FFN_PRIO"):
+    assert ctx.lib.ffd_tune(b"ffn_prio", int(os.environ["FFN_PRIO"])) == 0
 if os.environ.get("FFN_SPLIT") == "1":  # the opt-in bf16x3-split kernel (its packs are made by a first forward)
     from fastfourierdiffusion_amd.utils.dataclasses import DiffusableBatch
     assert ctx.lib.ffd_tune(b"ffn_split", 1) == 0
