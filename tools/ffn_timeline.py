@@ -53,4 +53,12 @@ out["cu_last_exit_us"] = q(last)
 late = [k for k, v in cus.items() if max((r[i, 6] - t0) * tk for i in v) > np.percentile(last, 85)]
 out["late_cus_tiles"] = sorted(float(sum(r[i, 7] for i in cus[k])) for k in late)[:40]
 out["late_cus_workgroups"] = sorted(len(cus[k]) for k in late)[:40]
+# which block indices share a CU (record i belongs to blockIdx.x = i when every workgroup of the grid wrote one)
+diffs = {}
+for v in cus.values():
+    if len(v) == 2:
+        d = abs(v[0] - v[1])
+        diffs[d] = diffs.get(d, 0) + 1
+out["cu_pair_block_distance"] = dict(sorted(diffs.items(), key=lambda kv: -kv[1])[:6])
+out["first_on_cu_is_faster"] = int(sum(1 for v in cus.values() if len(v) == 2 and r[min(v), 6] < r[max(v), 6]))
 print(json.dumps(out))
