@@ -30,6 +30,7 @@ struct LstmLayer {
 
 struct LayerPacked {
   float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
+  float* ring = nullptr;  // weight ring pack of the row-owning FFN
   float *w1s = nullptr, *w2s = nullptr;  // bf16x3 packs of the opt-in split FFN, made on first use
   float *aw_full = nullptr, *aw_q = nullptr;    // per-head packs of the fused in-projection + attention kernel
   float *aw_full2 = nullptr, *aw_q2 = nullptr;  // same, per pair of heads (two-head workgroups)
@@ -221,6 +222,24 @@ int ffd_tune(const char* key, int value) {
   }
   if (!strcmp(key, "ffn_dynamic")) {  // persistent FFN: tiles from a device counter (1) or static round robin (0)
     g_ffn_dynamic = value ? 1 : 0;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rows")) {  // large-M FFN: row-owning waves + CU-shared weight ring (1, default) or k_ffn_ln (0)
+    g_ffn_rows = value ? 1 : 0;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rows_mb")) {
+    if (value != 1 && value != 2) return FFD_ERR_INVALID;
+    g_ffn_rows_mb = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rows_dbg")) {
+    g_ffn_rows_dbg = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rows_nw")) {
+    if (value != 0 && value != 8 && value != 12 && value != 16) return FFD_ERR_INVALID;
+    g_ffn_rows_nw = value;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_rem")) {
@@ -477,6 +496,8 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if ((rc = dev_alloc(ctx, &pk.w1p, dpack_floats(F, d)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w2p, w2pack_floats(d, F)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w2r, w2rem_floats(d, F)))) return rc;
+        if (ffn_rows_supported(d, F))
+          if ((rc = dev_alloc(ctx, &pk.ring, ffn_ring_floats(d, F)))) return rc;
       }
       float* in_w = W(pre + "self_attn.in_proj_weight");
       HIPCHECK(launch_pack_dweight(in_w, pk.in_wp, 3 * d, d, s));
@@ -495,6 +516,8 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
       HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
       HIPCHECK(launch_pack_w2rem(W(pre + "linear2.weight"), pk.w2r, d, F, s));
+      if (pk.ring)
+        HIPCHECK(launch_pack_ffn_ring(W(pre + "linear1.weight"), W(pre + "linear1.bias"), W(pre + "linear2.weight"), pk.ring, d, F, s));
       if (pk.w1s) HIPCHECK(launch_pack_ffn_split(W(pre + "linear1.weight"), W(pre + "linear2.weight"), pk.w1s, pk.w2s, d, F, s));
       LayerWeights& lw = ctx->layers[i];
       lw.in_w = in_w;
@@ -514,6 +537,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       lw.w1p = pk.w1p;
       lw.w2p = pk.w2p;
       lw.w2r = pk.w2r;
+      lw.ring = pk.ring;
       lw.w1s = pk.w1s;
       lw.w2s = pk.w2s;
     }
@@ -1249,6 +1273,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
       else if (tr && mid_path_splits((int)M, m.d_model, m.dim_feedforward))
         name = "k_ffn_part", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
+      else if (tr && ffn_rows_selected((int)M, m.d_model, m.dim_feedforward))
+        name = "k_ffn_rows", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       else if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       break;
     case FFD_K_ATTN:  // in-projection (Q only on a pure-cache step) + QK^T + PV; x in, attention output out

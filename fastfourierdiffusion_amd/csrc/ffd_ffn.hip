@@ -531,6 +531,7 @@ hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M,
                          unsigned long long* stamp, int* tile_ctr) {
   if (M <= 0) return hipSuccess;
   if (F % 64 != 0) return hipErrorInvalidValue;
+  if (w.ring != nullptr && ffn_rows_selected(M, D, F)) return launch_ffn_rows(X, w, Y, M, D, F, s, stamp);
   switch (D) {
 #define X(d) \
     case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp, tile_ctr);

@@ -53,6 +53,7 @@ struct LayerWeights {
   const float *w1p;     // dpack (F x d)
   const float *w2p;     // w2pack
   const float *w2r;     // w2rem (remainder rows d % 16 of linear2.weight, 4x4x1 MFMA A-operand order)
+  const float* ring = nullptr;  // CU-shared weight ring pack of the row-owning FFN (ffd_ffn_rows.hip)
   const void *w1s = nullptr, *w2s = nullptr;  // three-part bf16 packs of the opt-in split FFN (ffd_ffn_split.hip)
 };
 
@@ -110,6 +111,14 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                          unsigned long long* stamp = nullptr, int* tile_ctr = nullptr);
 int ffn_tile_rows(int M);
+// Row-owning FFN with a CU-shared LDS weight ring (ffd_ffn_rows.hip): the large-M form
+bool ffn_rows_supported(int D, int F);
+bool ffn_rows_selected(int M, int D, int F);
+size_t ffn_ring_floats(int D, int F);
+hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
+hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
+                           unsigned long long* stamp = nullptr);
+extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_mb, g_ffn_rows_dbg;
 // Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
 // workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
 int small_path_splits(int M, int D, int F);

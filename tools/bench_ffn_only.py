@@ -10,6 +10,11 @@ wl = sys.argv[3] if len(sys.argv) > 3 else "ecg"
 model, sch, sd = bench.build_model(torch.device("cuda", 0), wl)
 ctx = model._ctx(); lib = ctx.lib
 lib.ffd_tune(b"ffn_mb", mb)
+if os.environ.get("FFN_ROWS") is not None:
+    assert lib.ffd_tune(b"ffn_rows", int(os.environ["FFN_ROWS"])) == 0
+for kv in os.environ.get("FFD_TUNE", "").split(","):
+    if kv:
+        assert lib.ffd_tune(kv.split("=")[0].encode(), int(kv.split("=")[1])) == 0, kv
 ms = C.c_float()
 N.check(lib.ffd_bench_ffn(ctx.handle, B, 10, C.byref(ms), None), ctx.handle)
 fl = lib.ffd_ffn_flops_per_launch(ctx.handle, B)
