@@ -43,12 +43,8 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
                                                   const float* __restrict__ W2r, const float* __restrict__ b2,
                                                   const float* __restrict__ gam, const float* __restrict__ bet,
-                                                  float* __restrict__ Y, int M, int F, int stagger,
-                                                  unsigned long long* __restrict__ stamp, int* __restrict__ tile_ctr) {
-  // tile_ctr (persistent form; nullptr = static round robin): [0] next unassigned tile - gridDim.x, [1] workgroups
-  // that have exited.  Tiles are handed out dynamically: in-kernel timestamps showed 10-20 % of the workgroups of a
-  // statically partitioned launch finishing 60-70 us after the median (the launch then waits for them with most CUs
-  // idle).  The tile -> workgroup map never shows in the result (fixed reduction order inside a tile).
+                                                  float* __restrict__ Y, int M, int F,
+                                                  unsigned long long* __restrict__ stamp) {
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): shader-clock and 100 MHz real-time
   // deltas around the main loops, written to memory nothing else reads (MI355X_MICROARCH.md, DVFS item 6)
   constexpr int S = lds_stride(D);
@@ -70,18 +66,12 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   constexpr int NRED = DMA ? 2 : 3;  // partial-sum buffers (the persistent form trades one for the second X image)
   __shared__ __align__(16) float xsb[NBUF * R * SX];
   __shared__ __align__(16) float red[NRED * R * S2];
-  __shared__ int s_next;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ntiles = (M + R - 1) / R;
-  const bool prio_epilogue = (stagger & 0x40000000) != 0;  // (launcher flags folded into the stagger argument)
-  const bool prio_alternate = (stagger & 0x20000000) != 0;
-  const bool prio_opposed = (stagger & 0x10000000) != 0;  // ... and the two wave slots of a SIMD in opposite phase
-  stagger &= 0x0FFFFFFF;
-  const int prio_phase = prio_opposed ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u) : 0;  // HW_ID wave slot
 
   // a tile's X rows -> image `b`, asynchronously (rows past M repeat the last valid row; they are never stored)
   auto issue_dma = [&](int t, int b) {
@@ -100,7 +90,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 
   int tile = blockIdx.x;
   int buf = 0;
-  if (DMA && tile_ctr && threadIdx.x == 0) s_next = (int)gridDim.x + atomicAdd(tile_ctr, 1);  // read after the first barrier
   if (DMA) {
     issue_dma(tile, 0);
   } else {
@@ -145,14 +134,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   };
   load_w1(0);
   load_w2(0);
-  // De-phase the two waves that share a SIMD (they come from two workgroups that start together and
-  // run the same instruction stream, so without this they also stall together): the wave in the odd
-  // hardware wave slot starts its first main loop `stagger` x 64 cycles late.
-  if (stagger > 0) {
-    const unsigned hwid = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);  // HW_REG_HW_ID[3:0] = wave slot in the SIMD
-    if (hwid & 1)
-      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
-  }
   // stamp record of a workgroup (8 x u64): [0] sum of shader-clock deltas over its main loops, [1] the same in 10 ns
   // real-time ticks, [2] real time at entry, [3] / [4] begin / end of its first main loop, [5] end of its first
   // epilogue, [6] exit, [7] tiles processed.  s_memrealtime is one chip-wide 100 MHz counter: a launch timeline.
@@ -171,11 +152,8 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int s = 0; s < KS; ++s) xf[mb][s] = xs[(16 * mb + (lane & 15)) * SX + 4 * s + (lane >> 4)];
-    const int tile_next = (DMA && tile_ctr) ? s_next : tile + (int)gridDim.x;
+    const int tile_next = tile + (int)gridDim.x;
     if (DMA && tile_next < ntiles) issue_dma(tile_next, buf ^ 1);
-    // request the tile after next now; the answer is parked in s_next after the reduction barrier below
-    int tile_req = 0;
-    if (DMA && tile_ctr && threadIdx.x == 0 && tile_next < ntiles) tile_req = atomicAdd(tile_ctr, 1);
 
     f32x4 yacc[CT][MB];
 #pragma unroll
@@ -188,18 +166,11 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (prio_epilogue) __builtin_amdgcn_s_setprio(0);
     if (stamp) {  // scalar: stays in SGPRs
       st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
       if (st_tiles == 0) st_first_b = st_rt;
     }
     for (int ci = 0; ci < nchunk; ++ci) {
-      // (experiment, ffd_tune "ffn_prio" = 2: the wave alternates between two priorities every four chunks, so that
-      //  neither of the two workgroups of a CU owns the issue slots for a whole launch)
-      if (prio_alternate && (ci & 3) == 0) {
-        if (((ci >> 2) ^ prio_phase) & 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-      }
       const int nx = (ci + 1 < nchunk) ? ci + 1 : 0;  // the last prefetch wraps to chunk 0 = the next tile's first chunk
       // GEMM1: H^T chunk (16 hidden x 16*MB rows), K = D; bias is the initial accumulator
       f32x4 h[MB];
@@ -253,10 +224,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
       if (st_tiles == 0) st_first_e = rt;
     }
 
-    // Outside the main loop this wave competes with the other resident workgroup's MFMA stream for issue slots and
-    // was measured starving (epilogue 4-5 us alone, 26 us beside a main loop): raise its priority until it is back in
-    // its own main loop, so the pair spends more of the time in the 98 %-busy both-in-main-loop regime.
-    if (prio_epilogue) __builtin_amdgcn_s_setprio(3);
     // ---- deterministic cross-wave reduction through LDS, fixed order of additions:
     //   3 buffers (small M): wave 0 adds its partial into the X tile (= the residual), waves 1..3 park theirs;
     //                        row sum = ((((x + p0) + p1) + p2) + p3) + b2
@@ -339,7 +306,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     if (wave == 0) put_partial(xs, SX, true);
     else if (wave <= NRED) put_partial(red + (size_t)(wave - 1) * R * S2, S2, false);
     __syncthreads();
-    if (DMA && tile_ctr && threadIdx.x == 0) s_next = (int)gridDim.x + tile_req;  // every thread has read s_next by now
     if (NRED == 2) {
       if (wave == 3) put_partial(red, S2, true);
       __syncthreads();
@@ -445,13 +411,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     // (the barrier at the top of the next iteration orders this tile's LDS reads before the next reduction's
     //  writes: the images alternate, and `red` is next written after that barrier)
   }
-  if (DMA && tile_ctr && threadIdx.x == 0) {
-    // the last workgroup out re-arms the counters for the next launch (all others are past their last access)
-    if (atomicAdd(tile_ctr + 1, 1) == (int)gridDim.x - 1) {
-      tile_ctr[0] = 0;
-      tile_ctr[1] = 0;
-    }
-  }
   if (stamp && threadIdx.x == 0) {
     unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
     o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
@@ -460,8 +419,6 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   }
 }
 
-int g_ffn_prio = 0;         // 1: waves outside their main loop run at raised priority (ffd_tune "ffn_prio")
-int g_ffn_dynamic = 0;      // 1: the persistent grid takes tiles from a device counter; 0: static round robin
 int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
 int num_cus() {
   static int n = 0;
@@ -473,13 +430,12 @@ int num_cus() {
   }
   return n;
 }
-int g_ffn_stagger = -1;     // x64 cycles of start delay for the odd wave slot of each SIMD; -1 = heuristic (ffd_tune "ffn_stagger")
 int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
 int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
 
 template <int D>
 static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
-                               unsigned long long* stamp, int* tile_ctr) {
+                               unsigned long long* stamp) {
   // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
   // and is the default once the grid fills the chip; smaller tiles for small batches.
   int mb = g_ffn_mb_override;
@@ -487,13 +443,6 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     const int target = 2 * 256;
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
-  // Start stagger of the odd wave slot (ffd_tune "ffn_stagger", x64 cycles): 0.  Round 1 de-phased the two resident
-  // workgroups of a CU by 11 D x 64 cycles (469 -> 457 us then); with the persistent grid and the float4 epilogue the
-  // ECG step is fastest without it (5.89 ms against 5.92 at 792, 5.98 at 2900: tools/probes/step_ab.py).  The per-CU
-  // timeline (tools/ffn_timeline.py) shows why de-phasing cannot help: of the two workgroups of a CU one gets the
-  // issue slots (3 tiles by 365 us), the other trails (440 us) -- 73 us per tile shared, 71 alone.
-  const int stagger = (g_ffn_stagger >= 0 ? (g_ffn_stagger & 0x0FFFFFFF) : 0) | (g_ffn_prio == 1 ? 0x40000000 : 0) |
-                      (g_ffn_prio >= 2 ? 0x20000000 : 0) | (g_ffn_prio == 3 ? 0x10000000 : 0);
   dim3 block(256);
   // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
   const int resident = num_cus() * (mb == 4 ? 2 : 1) * (g_ffn_persist > 0 ? g_ffn_persist : 1);
@@ -501,15 +450,14 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
     const int ntiles = cdiv(M, 16 * mbv);
     return dim3((mbv >= 4 && g_ffn_persist != 0 && ntiles > resident) ? resident : ntiles);
   };
-  if (g_ffn_dynamic == 0) tile_ctr = nullptr;
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
     if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,             \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp, tile_ctr);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp);                                      \
     else                                                                                                          \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,            \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stagger, stamp, tile_ctr);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp);                                      \
   } while (0)
   switch (mb) {
     case 8: FFD_LAUNCH_FFN(8); break;
@@ -528,13 +476,13 @@ int ffn_tile_rows(int M) {  // rows per workgroup launch_ffn_ln picks (one stamp
 }
 
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
-                         unsigned long long* stamp, int* tile_ctr) {
+                         unsigned long long* stamp) {
   if (M <= 0) return hipSuccess;
   if (F % 64 != 0) return hipErrorInvalidValue;
   if (w.ring != nullptr && ffn_rows_selected(M, D, F)) return launch_ffn_rows(X, w, Y, M, D, F, s, stamp);
   switch (D) {
 #define X(d) \
-    case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp, tile_ctr);
+    case d: return launch_ffn_d<d>(X, w, Y, M, F, s, stamp);
     FFD_D_LIST(X)
 #undef X
     default: return hipErrorInvalidValue;

@@ -2,64 +2,66 @@
 //     Y = LayerNorm2( X + W2 relu(W1 X + b1) + b2 )
 // Row-owning waves + a CU-shared weight ring (round 3; replaces the F-split workgroup of k_ffn_ln at large M).
 //
-//   * Every wave owns 16*MB rows and walks the WHOLE hidden dimension: its Y^T accumulators hold complete rows, so
-//     b2 + residual + LayerNorm2 happen in registers (a lane has 4 consecutive columns of one row per 16-column tile;
-//     a row is spread over the 4 lane quarters: two xor-shuffles per statistic) and rows leave as float4 stores.
-//     No partial tiles through LDS, no reduction barriers, nothing that crawls beside another wave's MFMA stream.
-//   * The weights are streamed ONCE PER CU: a ring of NSLOT slots in LDS, one slot = the packed fragments of 32 hidden
-//     units (W1 rows, W2 columns, b1) in exactly the order the waves consume them, filled by LDS-DMA
-//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs) three slots ahead and read by all NW waves with
-//     ds_read_b128 (one read = the A operands of 4 MFMAs per row block).
-//   * One s_barrier per slot, placed BETWEEN the two products of the slot: the fragments the first MFMAs after the
-//     barrier need are already in registers, and the slot boundary itself has no barrier (the next slot's first
-//     fragments are requested under the current slot's last MFMAs).  The barrier certifies slot i+1 (every wave waits
-//     for its own DMA pieces with a counted vmcnt first) and frees slot i-1.
-//   * GEMM1 computes H^T chunks for two 16-wide chunks at once (two independent accumulator chains per row block);
-//     relu'd accumulators are GEMM2's B operand as in k_ffn_ln; the d % 16 remainder columns run on
-//     v_mfma_f32_4x4x1_16b_f32.
-//   * Persistent: one workgroup per CU walks tiles of 16*MB*NW rows; the weight stream simply wraps around.  The
-//     next tile's X rows arrive by LDS-DMA into the wave's own image while the current tile computes.
-// Summation order per output element is fixed (hidden units ascending), independent of grid and tile assignment.
+//   * Every wave owns 32 rows and walks the WHOLE hidden dimension on v_mfma_f32_32x32x2_f32 (64 cycles per
+//     instruction: half the instructions per FLOP of the 16x16x4 form, and a single accumulation chain already runs
+//     at the issue rate, so one wave per SIMD can keep the matrix pipe busy on its own).  Its Y^T accumulators hold
+//     complete rows, so b2 + residual + LayerNorm2 happen in registers (a lane has 4 consecutive columns of one row
+//     per 8-column group; a row is spread over the two lane halves: one xor-shuffle per statistic) and rows leave as
+//     float4 stores.  No partial tiles through LDS, no reduction barriers.
+//   * The weights are streamed ONCE PER CU: a ring of NSLOT slots in LDS, one slot = the packed fragments of 32 CPS
+//     hidden units (W1 rows, W2 columns, b1) in exactly the order the waves consume them, filled by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no VGPRs) NSLOT-1 slots ahead and read by all NW waves
+//     with ds_read_b128 (one read = the A operands of 4 MFMAs), PD reads ahead of their MFMAs.
+//   * One s_barrier per slot, placed BETWEEN the two products of the slot's last chunk: the fragments the first MFMAs
+//     after the barrier need are already in registers, and the slot boundary itself has no barrier.  The barrier
+//     certifies slot i+1 (every wave waits for its own DMA pieces with a counted vmcnt first) and frees slot i-1.
+//   * relu'd GEMM1 accumulators are GEMM2's B operand (register r of the 32x32 accumulator = hidden units
+//     f_r and f_r + 4 of the two lane halves, f_r = (r & 3) + 8 (r >> 2): a valid k pair); the d % 32 remainder
+//     columns run on v_mfma_f32_4x4x1_16b_f32, all of a chunk's together (switching between the two MFMA forms
+//     instruction by instruction was measured at 47 cycles per 4x4x1 instead of 8).
+//   * Persistent: one workgroup per CU walks tiles of 32 NW rows; the weight stream simply wraps around.
+// Summation order per output element is fixed (hidden units in packed order), independent of grid and tile assignment.
 #include "ffd_internal.h"
 
 namespace ffd {
 
-// ---- ring pack: [F/32 slots][SLOT_G groups][64 lanes][4], groups in the order the waves consume them ------------
-//   groups 0 .. NQ1-1             W1 stream of the chunk pair, item idx = 4 g + j: k-step s = idx / 2, chunk ch = idx % 2
-//                                 = W1[32 p + 16 ch + (lane & 15)][4 s + (lane >> 4)]
-//   CT groups per chunk ch = 0, 1 (chunk 0's first), item idx: r = idx / CT, ct = idx % CT
-//                                 = W2[16 ct + (lane & 15)][32 p + 16 ch + 4 (lane >> 4) + r]
-//   NG groups per chunk ch = 0, 1 (4x4x1 A operands), item idx: r = idx / NG, g = idx % NG
-//                                 = W2[16 CT + 4 g + (lane & 3)][32 p + 16 ch + 4 (lane >> 4) + r]
-//   last group                    lanes 0..7: b1[32 p + 4 lane + j]
-constexpr __host__ __device__ int ring_ct(int D) { return D / 16; }
-constexpr __host__ __device__ int ring_ng(int D) { return (D % 16) / 4; }
-constexpr __host__ __device__ int ring_nq1(int D) { return cdiv(2 * (D / 4), 4); }
-constexpr __host__ __device__ int ring_slot_groups(int D) { return ring_nq1(D) + 2 * (ring_ct(D) + ring_ng(D)) + 1; }
-size_t ffn_ring_floats(int D, int F) { return (size_t)(F / 32) * ring_slot_groups(D) * 256; }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---- ring pack: [F/32 chunks][SGC groups][64 lanes][4], groups in the order the waves consume them ---------------
+// MFMA 32x32x2 operands: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
+//                        C/D lane l reg r = D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31]
+//   groups 0 .. NQ1-1   W1 stream of chunk p, item idx = 4 g + j = k-step s:   W1[32 p + (lane & 31)][2 s + (lane >> 5)]
+//   4 CT groups         item idx: r = idx / CT, ct = idx % CT:   W2[32 ct + (lane & 31)][32 p + f_r + 4 (lane >> 5)]
+//   4 NG groups         (4x4x1 A operands) item idx: r = idx / NG, g = idx % NG:
+//                                                        W2[32 CT + 4 g + (lane & 3)][32 p + f_r + 4 (lane >> 5)]
+//   last group          lanes 0..7: b1[32 p + 4 lane + j]
+constexpr __host__ __device__ int ring_ct(int D) { return D / 32; }
+constexpr __host__ __device__ int ring_ng(int D) { return (D % 32) / 4; }
+constexpr __host__ __device__ int ring_nq1(int D) { return cdiv(D / 2, 4); }
+constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nq1(D) + 4 * (ring_ct(D) + ring_ng(D)) + 1; }
+size_t ffn_ring_floats(int D, int F) { return (size_t)(F / 32) * ring_chunk_groups(D) * 256; }
 
 __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __restrict__ b1,
                                 const float* __restrict__ W2, float* __restrict__ out, int D, int F) {
-  const int KS = D / 4, CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D), SG = ring_slot_groups(D);
+  const int KS2 = D / 2, CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D), SG = ring_chunk_groups(D);
   const size_t total = (size_t)(F / 32) * SG * 256;
   for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(o & 3), lane = (int)((o >> 2) & 63);
     const int g = (int)((o >> 8) % SG), p = (int)((o >> 8) / SG);
+    const int half = lane >> 5;
     float v = 0.f;
     if (g < NQ1) {
-      const int idx = 4 * g + j;
-      if (idx < 2 * KS) {
-        const int s = idx >> 1, ch = idx & 1;
-        v = W1[(size_t)(32 * p + 16 * ch + (lane & 15)) * D + 4 * s + (lane >> 4)];
-      }
-    } else if (g < NQ1 + 2 * CT) {
-      const int gg = g - NQ1, ch = gg / CT, w = gg % CT;
-      const int idx = 4 * w + j, r = idx / CT, ct = idx % CT;
-      v = W2[(size_t)(16 * ct + (lane & 15)) * F + 32 * p + 16 * ch + 4 * (lane >> 4) + r];
+      const int s = 4 * g + j;
+      if (s < KS2) v = W1[(size_t)(32 * p + (lane & 31)) * D + 2 * s + half];
+    } else if (g < NQ1 + 4 * CT) {
+      const int idx = 4 * (g - NQ1) + j, r = idx / CT, ct = idx % CT;
+      v = W2[(size_t)(32 * ct + (lane & 31)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
     } else if (g < SG - 1) {
-      const int gg = g - NQ1 - 2 * CT, ch = gg / NG, w = gg % NG;
-      const int idx = 4 * w + j, r = idx / NG, gq = idx % NG;
-      v = W2[(size_t)(16 * CT + 4 * gq + (lane & 3)) * F + 32 * p + 16 * ch + 4 * (lane >> 4) + r];
+      const int idx = 4 * (g - NQ1 - 4 * CT) + j, r = idx / NG, gq = idx % NG;
+      v = W2[(size_t)(32 * CT + 4 * gq + (lane & 3)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
     } else if (lane < 8) {
       v = b1[32 * p + 4 * lane + j];
     }
@@ -84,7 +86,8 @@ __device__ __forceinline__ void wait_vm() {
 // next ds_read of the same __shared__ array (it cannot tell the ring's slots apart), which drains the ring every slot.
 // The kernel orders DMA and reads itself: counted vmcnt + s_barrier (see the slot barrier below).
 __device__ __forceinline__ void dma_piece(const float* g, unsigned lds_byte) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g) : "memory");  // (m0 is a reserved register: hipcc keeps nothing in it across statements)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g)
+               : "memory");  // (m0 is a reserved register: hipcc keeps nothing in it across statements)
 }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
   return (unsigned)(unsigned long)((const __attribute__((address_space(3))) float*)p);
@@ -92,220 +95,200 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) {
 
 __device__ __forceinline__ float f4e(const float4& q, int j) { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
 
-template <int D, int MB, int NW, int NSLOT>
+template <int D, int NW, int CPS, int NSLOT>
 struct FfnRowsCfg {
-  static constexpr int KS = D / 4;
+  static constexpr int KS2 = D / 2;
   static constexpr int CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D);
-  static constexpr int SG = ring_slot_groups(D);
-  static constexpr int SLOT_FLOATS = SG * 256;
-  static constexpr int SX4 = D / 4 + 1;                      // float4 slots per row of the X image (one pad slot)
-  static constexpr int SX = 4 * SX4;
-  static constexpr int NPX = cdiv(16 * MB * SX4, 64);        // 1 KiB DMA pieces per wave image
-  static constexpr int XIMG_FLOATS = NPX * 256;
+  static constexpr int SGC = ring_chunk_groups(D);           // 1 KiB groups per chunk (the last one: bias)
+  static constexpr int NFC = SGC - 1;                        // fragment groups of a chunk
+  static constexpr int SLOT_G = CPS * SGC;
+  static constexpr int SLOT_FLOATS = SLOT_G * 256;
   static constexpr int LNP = 3 * D;                          // b2, gamma, beta
   static constexpr int LNP_PAD = cdiv(LNP, 4) * 4;
-  static constexpr int LDS_FLOATS = NSLOT * SLOT_FLOATS + NW * XIMG_FLOATS + LNP_PAD;
-  static constexpr int NST = MB * (CT + (NG > 0 ? 1 : 0));   // float4 stores per lane in a tile epilogue
+  static constexpr int LDS_FLOATS = NSLOT * SLOT_FLOATS + LNP_PAD;
+  static constexpr int NST = 4 * CT + (NG + 1) / 2;          // float4 stores per lane in a tile epilogue (at most)
   static constexpr int AHEAD = NSLOT - 1;                    // a slot's DMA is issued AHEAD slots before its use
   static constexpr int PD = 3;                               // fragment groups requested ahead of their MFMAs
-  static constexpr int NPHI = cdiv(SG, NW), NPLO = SG / NW;  // DMA pieces of a slot per wave (waves < SG % NW: NPHI)
-  static_assert(NPHI + NST <= 63, "vmcnt range");
+  static constexpr int NPW = cdiv(SLOT_G, NW);               // DMA pieces of a slot per wave (the same for every wave: the
+                                                             // last pieces of a slot are fetched twice when NW does not divide)
+  static_assert((AHEAD - 2) * NPW + NST <= 63 && AHEAD >= 2, "vmcnt range");
+  static_assert(NPW <= NFC - NQ1, "one DMA piece per fragment group after the barrier");
+  static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
-template <int D, int MB, int NW, int NSLOT>
-__global__ __launch_bounds__(64 * NW, NW / 4) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
+template <int D, int NW, int CPS, int NSLOT>
+__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
                                                              const float* __restrict__ b2, const float* __restrict__ gam,
                                                              const float* __restrict__ bet, float* __restrict__ Y, int M,
-                                                             int F, int dbg, unsigned long long* __restrict__ stamp) {
+                                                             int F, unsigned long long* __restrict__ stamp) {
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): the record k_ffn_ln writes (8 x u64 per
   // workgroup), to memory nothing else reads
-  using C = FfnRowsCfg<D, MB, NW, NSLOT>;
-  constexpr int KS = C::KS, CT = C::CT, NG = C::NG, NQ1 = C::NQ1, SG = C::SG;
+  using C = FfnRowsCfg<D, NW, CPS, NSLOT>;
+  constexpr int KS2 = C::KS2, CT = C::CT, NG = C::NG, NQ1 = C::NQ1, SGC = C::SGC, NFC = C::NFC, PD = C::PD;
   constexpr int NGA = NG > 0 ? NG : 1, CTA = CT > 0 ? CT : 1;
-  constexpr int R = 16 * MB * NW;
+  constexpr int R = 32 * NW;
+  constexpr int NFS = CPS * NFC;  // fragment groups of a slot
+  constexpr int RPG = cdiv(4, CTA);  // accumulator registers (k pairs) one GEMM2 fragment group covers
+  static_assert(CT == 0 || 4 % CT == 0, "relu placement assumes CT in {1, 2, 4}");
   __shared__ __align__(16) float lds[C::LDS_FLOATS];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int q = lane >> 4, m = lane & 15;
+  const int half = lane >> 5, m = lane & 31;
   float* const ringl = lds;
-  float* const ximg = lds + NSLOT * C::SLOT_FLOATS + wave * C::XIMG_FLOATS;
-  float* const lnp = lds + NSLOT * C::SLOT_FLOATS + NW * C::XIMG_FLOATS;
+  float* const lnp = lds + NSLOT * C::SLOT_FLOATS;
   const unsigned ring_base = __builtin_amdgcn_readfirstlane(lds_addr(ringl));
-  const unsigned ximg_base = __builtin_amdgcn_readfirstlane(lds_addr(ximg));
 
   const int ntiles = (M + R - 1) / R;
-  const int NSL = F / 32;  // slots per tile
+  const int NSL = F / (32 * CPS);  // slots per tile
   const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * NSL;
   if (total == 0) return;  // (uniform over the workgroup)
-  int np = 0;  // DMA pieces of a slot this wave issues
-  for (int g = wave; g < SG; g += NW) ++np;
 
   auto issue_ring = [&](int wslot, int rslot) {  // packed slot `wslot` of the layer -> ring slot `rslot`
     const float* src = ring + (size_t)wslot * C::SLOT_FLOATS + lane * 4;
     const unsigned dst = ring_base + (unsigned)rslot * (C::SLOT_FLOATS * 4);
-    for (int g = wave; g < SG; g += NW) dma_piece(src + g * 256, dst + g * 1024);
-  };
-  auto issue_x = [&](int tile) {  // this wave's rows of `tile` -> its image (rows past M repeat row M-1; never stored)
-    const int row0 = tile * R + wave * 16 * MB;
-#pragma unroll
-    for (int pc = 0; pc < C::NPX; ++pc) {
-      const int p = pc * 64 + lane;
-      const int r = min(p / C::SX4, 16 * MB - 1), c4 = min(p % C::SX4, D / 4 - 1);
-      const int rr = min(row0 + r, M - 1);
-      dma_piece(X + (size_t)rr * D + 4 * c4, ximg_base + pc * 1024);
-    }
+    for (int g = wave; g < C::SLOT_G; g += NW) dma_piece(src + g * 256, dst + g * 1024);
   };
 
-  // ---- prologue: LN parameters, first X image, first AHEAD slots ----
+  // ---- prologue: LN parameters, first AHEAD slots ----
   for (int i = threadIdx.x; i < C::LNP; i += 64 * NW) lnp[i] = i < D ? b2[i] : i < 2 * D ? gam[i - D] : bet[i - 2 * D];
-  issue_x(blockIdx.x);
 #pragma unroll
   for (int j = 0; j < C::AHEAD; ++j)
     if (j < total) issue_ring(j % NSL, j % NSLOT);
-  // slot 0 landed (and the X image, which is older); slots 1 .. AHEAD-1 may still be in flight
-  if (total >= (int)C::AHEAD && C::AHEAD == 3) {
-    if (np == C::NPHI) wait_vm<2 * C::NPHI>(); else wait_vm<2 * C::NPLO>();
-  } else {
-    wait_vm<0>();
-  }
+  wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LN parameter writes
   __builtin_amdgcn_s_barrier();
 
-  float xf[MB][KS];
-  float4 xres[MB][CTA], xrem[MB];
-  f32x4 yacc[CTA][MB], yrem[NGA][MB];
+  float xf[KS2];
+  f32x16 yacc[CTA];
+  f32x4 yrem[NGA];
   int tile = blockIdx.x, sl = 0;
   int wnext = C::AHEAD % NSL;  // packed slot the next ring DMA fetches
-  // The slot is consumed as a stream of NFR fragment groups (one ds_read_b128 each = the A operands of 4 MFMAs per
-  // row block); group k is requested PD groups before its MFMAs, across the slot boundary too (the first PD groups and
-  // the two bias fragments of a slot are requested under the previous slot's last MFMAs).
-  constexpr int NFR = SG - 1, PD = C::PD;
-  float4 hb[2], f[NFR + PD];
+  // The slot is consumed as a stream of NFS fragment groups (one ds_read_b128 each = the A operands of 4 MFMAs);
+  // group k is requested PD groups before its MFMAs, across chunk and slot boundaries too (the first PD groups and
+  // the bias fragments of a chunk are requested under the previous chunk's last MFMAs).
+  float4 hb[4], f[NFS + PD];
   {
     const float* slot = ringl;
-    hb[0] = *reinterpret_cast<const float4*>(slot + NFR * 256 + 4 * q);
-    hb[1] = *reinterpret_cast<const float4*>(slot + NFR * 256 + 16 + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(slot + NFC * 256 + 4 * (2 * t + half));
 #pragma unroll
     for (int k = 0; k < PD; ++k) f[k] = *reinterpret_cast<const float4*>(slot + k * 256 + lane * 4);
   }
   unsigned long long st_clk = 0, st_rt = 0, st_acc = 0, st_acc_rt = 0, st_first_b = 0, st_first_e = 0, st_epi = 0;
   const unsigned long long st_entry = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
   int st_tiles = 0;
-  const bool late_dma = wave >= NW / 2;  // the second wave of each SIMD issues its DMA pieces a few MFMA groups later
 
   for (int it = 0; it < total; ++it) {
-    const float* slot = ringl + (it % NSLOT) * C::SLOT_FLOATS + lane * 4;
-    const float* nslot = ringl + ((it + 1) % NSLOT) * C::SLOT_FLOATS + lane * 4;
-    if (sl == 0) {  // ---- tile start: B fragments + residual from the wave's image ----
+    const float* slot = ringl + (it % NSLOT) * C::SLOT_FLOATS;
+    const float* nslot = ringl + ((it + 1) % NSLOT) * C::SLOT_FLOATS;
+    if (sl == 0) {  // ---- tile start: B fragments + residual rows straight from global memory (once per 32 NW rows) ----
       if (stamp) {
         st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
         if (st_tiles == 0) st_first_b = st_rt;
       }
+      const int row = min(tile * R + wave * 32 + m, M - 1);  // rows past M repeat row M-1; they are never stored
+      const float* xr = X + (size_t)row * D;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
+      for (int s = 0; s < KS2; ++s) xf[s] = xr[2 * s + half];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xf[mb][s] = ximg[(16 * mb + m) * C::SX + 4 * s + q];
+      for (int ct = 0; ct < CTA; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-          xres[mb][ct] = *reinterpret_cast<const float4*>(&ximg[(16 * mb + m) * C::SX + 16 * ct + 4 * q]);
-        xrem[mb] = float4{0.f, 0.f, 0.f, 0.f};
-        if (NG > 0 && q < NG) xrem[mb] = *reinterpret_cast<const float4*>(&ximg[(16 * mb + m) * C::SX + 16 * CT + 4 * q]);
+        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CTA; ++ct) yacc[ct][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < NGA; ++g) yrem[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // Retire these loads HERE: left to itself hipcc waits for them with counted vmcnt in front of the first MFMAs
+      // of the loop body, in EVERY iteration (it cannot know the loads are not re-issued), and those counts also
+      // drain the ring's LDS-DMA pieces, which share the counter: the ring then runs one slot deep.
 #pragma unroll
-        for (int g = 0; g < NGA; ++g) yrem[g][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int s = 0; s < KS2; ++s) asm volatile("" : "+v"(xf[s]));
     }
-    f32x4 h[2][MB];
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) h[ch][mb] = f32x4{hb[ch].x, hb[ch].y, hb[ch].z, hb[ch].w};
+    f32x16 h;
 
-    auto issue_dma = [&]() {
-      if (sl == 0 && tile + (int)gridDim.x < ntiles) issue_x(tile + gridDim.x);  // (this tile's fragments are in registers)
-      if (it + C::AHEAD < total && !(dbg & 4)) {
-        issue_ring(wnext, (it + C::AHEAD) % NSLOT);
-        if (++wnext == NSL) wnext = 0;
+    // The DMA pieces of slot it + AHEAD go out one per fragment group after the slot's barrier (an LDS-DMA issue holds
+    // the wave for 60-180 cycles: one fits in the shadow of a 64-cycle MFMA, a burst of them does not).
+    const bool dma_on = it + C::AHEAD < total;
+    const float* dma_src = ring + (size_t)wnext * C::SLOT_FLOATS + lane * 4;
+    const unsigned dma_dst = ring_base + (unsigned)((it + C::AHEAD) % NSLOT) * (C::SLOT_FLOATS * 4);
+    int dma_g = wave;  // next piece of the slot this wave issues
+    auto issue_piece = [&]() {  // (a piece index past the slot wraps to a piece some other wave also fetches)
+      if (dma_on) {
+        const int g = dma_g < C::SLOT_G ? dma_g : dma_g - C::SLOT_G;
+        dma_piece(dma_src + g * 256, dma_dst + g * 1024);
+        dma_g += NW;
       }
     };
 #pragma unroll
-    for (int k = 0; k < NFR; ++k) {
-      // request group k + PD (of the next slot once past the end: certified by this iteration's barrier)
-      if (k + PD < NFR) f[k + PD] = *reinterpret_cast<const float4*>(slot + (k + PD) * 256);
-      else f[k + PD] = *reinterpret_cast<const float4*>(nslot + (k + PD - NFR) * 256);
-      if (k == NFR - 1) {
-        hb[0] = *reinterpret_cast<const float4*>(nslot - lane * 4 + NFR * 256 + 4 * q);
-        hb[1] = *reinterpret_cast<const float4*>(nslot - lane * 4 + NFR * 256 + 16 + 4 * q);
+    for (int K = 0; K < NFS; ++K) {
+      const int c = K / NFC, k = K % NFC;  // chunk of the slot, group of the chunk (compile-time after unrolling)
+      const float4 w = f[K];
+      if (k == 0) {  // the bias is GEMM1's initial accumulator
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h[4 * t] = hb[t].x, h[4 * t + 1] = hb[t].y, h[4 * t + 2] = hb[t].z, h[4 * t + 3] = hb[t].w;
       }
-      __builtin_amdgcn_sched_barrier(0);
-      const float4 w = f[k];
-      if (k < NQ1) {
-        // ---- GEMM1: H^T chunks a, b (16 hidden x 16 MB rows each), K = D; the bias is the initial accumulator ----
+      // A group = 4 MFMAs (64 cycles each).  The wave's other work is placed in the gaps BETWEEN them, one kind per
+      // gap (an in-order wave cannot issue past an MFMA the pipe has not accepted yet, so only what sits in a gap
+      // hides under the preceding MFMA): gap 0 relu of the accumulator registers the next GEMM2 group reads, gap 1 the
+      // fragment read PD groups ahead, gap 2 one LDS-DMA piece.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int idx = 4 * k + j;
-          if (idx < 2 * KS) {
-            const int s = idx >> 1, ch = idx & 1;
+      for (int j = 0; j < 4; ++j) {
+        if (k < NQ1) {
+          // ---- GEMM1: H^T chunk (32 hidden x 32 rows), K = D ----
+          const int s = 4 * k + j;
+          if (s < KS2) h = mfma32(f4e(w, j), xf[s], h);
+        } else if (k < NQ1 + 4 * CT) {
+          // ---- GEMM2: Y^T += W2[:, chunk] relu(H^T chunk); accumulator register r is the k pair (f_r, f_r + 4) ----
+          const int idx = 4 * (k - NQ1) + j, r = idx / CTA, ct = idx % CTA;
+          yacc[ct] = mfma32(f4e(w, j), h[r], yacc[ct]);
+          if (j == 0) {  // relu (one v_med3_f32 (x, 0, +inf) per element)
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) h[ch][mb] = mfma16(f4e(w, j), xf[mb][s], h[ch][mb]);
+            for (int rr = 0; rr < RPG; ++rr) {
+              const int rn = (k - NQ1 + 1) * RPG + rr;
+              if (rn < 16) h[rn] = __builtin_amdgcn_fmed3f(h[rn], 0.f, __builtin_inff());
+            }
+          }
+        } else {
+          // remainder columns on the 4x4x1 form
+          const int idx = 4 * (k - NQ1 - 4 * CT) + j, r = idx / NGA, g = idx % NGA;
+          yrem[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4e(w, j), h[r], yrem[g], 0, 0, 0);
+        }
+        if (j == 1) {
+          // request group K + PD (of the next slot once past the end: certified by this iteration's barrier)
+          const int KP = K + PD;
+          const float* base = KP < NFS ? slot : nslot;
+          const int kk = KP < NFS ? KP : KP - NFS;
+          f[KP] = *reinterpret_cast<const float4*>(base + ((kk / NFC) * SGC + kk % NFC) * 256 + lane * 4);
+          if (k == NFC - 1) {  // bias fragments of the next chunk (of the next slot after the last chunk)
+            const float* bsrc = (c + 1 < CPS) ? slot + ((c + 1) * SGC + NFC) * 256 : nslot + NFC * 256;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(bsrc + 4 * (2 * t + half));
           }
         }
-        if (k == NQ1 - 1) {
-          // relu as one v_med3_f32 (x, 0, +inf) per element
+        if (j == 2 && K >= (CPS - 1) * NFC + NQ1 && K < (CPS - 1) * NFC + NQ1 + C::NPW) issue_piece();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (k == NQ1 - 1) {
+        // relu of the accumulator registers the first GEMM2 group reads
 #pragma unroll
-          for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) h[ch][mb][r] = __builtin_amdgcn_fmed3f(h[ch][mb][r], 0.f, __builtin_inff());
-          // ---- the slot's barrier: my pieces of slot it+1 have landed; afterwards slot it+1 is readable by everyone
-          //      and nobody reads slot it-1 any more ----
-          const bool steady = C::AHEAD == 3 && it + 2 < total;  // slot it+2 is in flight and may stay so
-          const bool stores = sl == 0 && it > 0;  // the previous tile's stores are younger than every DMA in flight
-          if (dbg & 2) {
-          } else if (steady) {
-            if (np == C::NPHI) {
-              if (stores) wait_vm<C::NPHI + C::NST>(); else wait_vm<C::NPHI>();
-            } else {
-              if (stores) wait_vm<C::NPLO + C::NST>(); else wait_vm<C::NPLO>();
-            }
+        for (int r = 0; r < RPG; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+        if (c == CPS - 1) {
+          // ---- the slot's barrier: my pieces of slot it+1 have landed; afterwards slot it+1 is readable by
+          //      everyone and nobody reads slot it-1 any more.  In flight and allowed to stay so: the slots after
+          //      it+1 that have been issued (it+2 .. it+AHEAD-1), and the previous tile's stores (younger) ----
+          if (C::AHEAD > 2 && it + C::AHEAD - 1 < total) {
+            if (sl == 0 && it > 0) wait_vm<(C::AHEAD - 2) * C::NPW + C::NST>(); else wait_vm<(C::AHEAD - 2) * C::NPW>();
           } else {
             wait_vm<0>();
           }
-          if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
-          if (!late_dma) issue_dma();
+          __builtin_amdgcn_s_barrier();
         }
-      } else if (k < NQ1 + 2 * CT) {
-        // ---- GEMM2: Y^T += W2[:, chunk] relu(H^T chunk); accumulator register r is the k-step ----
-        const int ch = (k - NQ1) / CTA, wi = (k - NQ1) % CTA;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int idx = 4 * wi + j, r = idx / CTA, ct = idx % CTA;
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) yacc[ct][mb] = mfma16(f4e(w, j), h[ch][mb][r], yacc[ct][mb]);
-        }
-        if (k == NQ1 + 1 && late_dma) issue_dma();
-      } else {
-        // remainder columns on the 4x4x1 form, all of the slot's together (switching between the two MFMA forms is
-        // expensive: interleaved one by one with the 16x16x4 ones they cost 47 cycles each instead of 8)
-        const int ch = (k - NQ1 - 2 * CT) / NGA, wi = (k - NQ1 - 2 * CT) % NGA;
-        if (!(dbg & 1)) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int idx = 4 * wi + j, r = idx / NGA, g = idx % NGA;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-              yrem[g][mb] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4e(w, j), h[ch][mb][r], yrem[g][mb], 0, 0, 0);
-          }
-        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int k = 0; k < PD; ++k) f[k] = f[NFR + k];
+    for (int k = 0; k < PD; ++k) f[k] = f[NFS + k];
+    if (dma_on && ++wnext == NSL) wnext = 0;
 
     if (++sl == NSL) {  // ---- tile end: + b2, + residual, LayerNorm2, float4 stores ----
       sl = 0;
@@ -315,80 +298,101 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ffn_rows(const float* __res
         st_acc_rt += rt - st_rt;
         if (st_tiles == 0) st_first_e = rt;
       }
-      const int row0 = tile * R + wave * 16 * MB;
+      // the residual rows again (L2 / MALL hits; re-read here rather than held in 36 registers through the tile)
+      float4 xres[CTA][4], xrem[(NGA + 1) / 2];
+      {
+        const float* xr = X + (size_t)min(tile * R + wave * 32 + m, M - 1) * D;
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        float4 v[CTA], vr = float4{0.f, 0.f, 0.f, 0.f};
-        float sum = 0.f;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float4 bq = *reinterpret_cast<const float4*>(&lnp[16 * ct + 4 * q]);
-          const float4 x4 = xres[mb][ct];
-          v[ct] = float4{x4.x + (yacc[ct][mb][0] + bq.x), x4.y + (yacc[ct][mb][1] + bq.y), x4.z + (yacc[ct][mb][2] + bq.z),
-                         x4.w + (yacc[ct][mb][3] + bq.w)};
-          sum += (v[ct].x + v[ct].y) + (v[ct].z + v[ct].w);
+          for (int t = 0; t < 4; ++t) xres[ct][t] = *reinterpret_cast<const float4*>(xr + 32 * ct + 8 * t + 4 * half);
+#pragma unroll
+        for (int i = 0; i < (NG + 1) / 2; ++i) {  // lane half h finishes remainder groups g = 2 i + h
+          xrem[i] = float4{0.f, 0.f, 0.f, 0.f};
+          if (2 * i + half < NG) xrem[i] = *reinterpret_cast<const float4*>(xr + 32 * CT + 4 * (2 * i + half));
         }
-        if (NG > 0) {
-          // the four lane quarters hold partial sums over their own hidden units: add them (all quarters get the total)
-          float t[NGA][4];
+      }
+      // yacc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]: four consecutive columns per (ct, t)
+      float4 v[CTA][4], vr[(NGA + 1) / 2];
+      float sum = 0.f;
 #pragma unroll
-          for (int g = 0; g < NG; ++g)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float a = yrem[g][mb][i];
-              a += __shfl_xor(a, 16);
-              a += __shfl_xor(a, 32);
-              t[g][i] = a;
+        for (int t = 0; t < 4; ++t) {
+          const float4 bq = *reinterpret_cast<const float4*>(&lnp[32 * ct + 8 * t + 4 * half]);
+          const float4 x4 = xres[ct][t];
+          v[ct][t] = float4{x4.x + (yacc[ct][4 * t] + bq.x), x4.y + (yacc[ct][4 * t + 1] + bq.y),
+                            x4.z + (yacc[ct][4 * t + 2] + bq.z), x4.w + (yacc[ct][4 * t + 3] + bq.w)};
+          sum += (v[ct][t].x + v[ct][t].y) + (v[ct][t].z + v[ct][t].w);
+        }
+      if (NG > 0) {
+        // the two lane halves hold partial sums over their own hidden units: add them (both halves get the total);
+        // half h then finishes groups g = 2 i + h
+#pragma unroll
+        for (int i = 0; i < (NG + 1) / 2; ++i) {
+          float a[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float t0 = yrem[2 * i][e];
+            t0 += __shfl_xor(t0, 32);
+            float t1 = 0.f;
+            if (2 * i + 1 < NG) {
+              t1 = yrem[(2 * i + 1 < NG) ? 2 * i + 1 : 0][e];
+              t1 += __shfl_xor(t1, 32);
             }
-          if (q < NG) {  // quarter q finishes remainder group g = q
-            float a[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              a[i] = 0.f;
-#pragma unroll
-              for (int g = 0; g < NG; ++g) a[i] = (g == q) ? t[g][i] : a[i];
-            }
-            const float4 bq = *reinterpret_cast<const float4*>(&lnp[16 * CT + 4 * q]);
-            const float4 x4 = xrem[mb];
-            vr = float4{x4.x + (a[0] + bq.x), x4.y + (a[1] + bq.y), x4.z + (a[2] + bq.z), x4.w + (a[3] + bq.w)};
-            sum += (vr.x + vr.y) + (vr.z + vr.w);
+            a[e] = half ? t1 : t0;
+          }
+          vr[i] = float4{0.f, 0.f, 0.f, 0.f};
+          if (2 * i + half < NG) {
+            const float4 bq = *reinterpret_cast<const float4*>(&lnp[32 * CT + 4 * (2 * i + half)]);
+            const float4 x4 = xrem[i];
+            vr[i] = float4{x4.x + (a[0] + bq.x), x4.y + (a[1] + bq.y), x4.z + (a[2] + bq.z), x4.w + (a[3] + bq.w)};
+            sum += (vr[i].x + vr[i].y) + (vr[i].z + vr[i].w);
           }
         }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / D);
-        float ss = 0.f;
+      }
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.0f / D);
+      float ss = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          const float a = v[ct].x - mean, b = v[ct].y - mean, c = v[ct].z - mean, d = v[ct].w - mean;
-          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c, c, ss), ss = fmaf(d, d, ss);
-        }
-        if (NG > 0 && q < NG) {
-          const float a = vr.x - mean, b = vr.y - mean, c = vr.z - mean, d = vr.w - mean;
-          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c, c, ss), ss = fmaf(d, d, ss);
-        }
-        ss += __shfl_xor(ss, 16);
-        ss += __shfl_xor(ss, 32);
-        const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
-        const int row = row0 + 16 * mb + m;
-        if (row < M) {
-          float* yr = Y + (size_t)row * D;
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + 16 * ct + 4 * q]);
-            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + 16 * ct + 4 * q]);
-            *reinterpret_cast<float4*>(yr + 16 * ct + 4 * q) =
-                float4{(v[ct].x - mean) * rstd * g4.x + e4.x, (v[ct].y - mean) * rstd * g4.y + e4.y,
-                       (v[ct].z - mean) * rstd * g4.z + e4.z, (v[ct].w - mean) * rstd * g4.w + e4.w};
-          }
-          if (NG > 0 && q < NG) {
-            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + 16 * CT + 4 * q]);
-            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + 16 * CT + 4 * q]);
-            *reinterpret_cast<float4*>(yr + 16 * CT + 4 * q) =
-                float4{(vr.x - mean) * rstd * g4.x + e4.x, (vr.y - mean) * rstd * g4.y + e4.y,
-                       (vr.z - mean) * rstd * g4.z + e4.z, (vr.w - mean) * rstd * g4.w + e4.w};
-          }
+        for (int t = 0; t < 4; ++t) {
+          const float a = v[ct][t].x - mean, b = v[ct][t].y - mean, c2 = v[ct][t].z - mean, d = v[ct][t].w - mean;
+          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
         }
+#pragma unroll
+      for (int i = 0; i < (NG + 1) / 2; ++i)
+        if (2 * i + half < NG) {
+          const float a = vr[i].x - mean, b = vr[i].y - mean, c2 = vr[i].z - mean, d = vr[i].w - mean;
+          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
+        }
+      ss += __shfl_xor(ss, 32);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+      const int row = tile * R + wave * 32 + m;
+      if (row < M) {
+        float* yr = Y + (size_t)row * D;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c0 = 32 * ct + 8 * t + 4 * half;
+            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + c0]);
+            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + c0]);
+            *reinterpret_cast<float4*>(yr + c0) =
+                float4{(v[ct][t].x - mean) * rstd * g4.x + e4.x, (v[ct][t].y - mean) * rstd * g4.y + e4.y,
+                       (v[ct][t].z - mean) * rstd * g4.z + e4.z, (v[ct][t].w - mean) * rstd * g4.w + e4.w};
+          }
+#pragma unroll
+        for (int i = 0; i < (NG + 1) / 2; ++i)
+          if (2 * i + half < NG) {
+            const int c0 = 32 * CT + 4 * (2 * i + half);
+            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + c0]);
+            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + c0]);
+            *reinterpret_cast<float4*>(yr + c0) =
+                float4{(vr[i].x - mean) * rstd * g4.x + e4.x, (vr[i].y - mean) * rstd * g4.y + e4.y,
+                       (vr[i].z - mean) * rstd * g4.z + e4.z, (vr[i].w - mean) * rstd * g4.w + e4.w};
+          }
       }
       if (stamp) {
         if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
@@ -405,22 +409,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_ffn_rows(const float* __res
   }
 }
 
-int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln
-int g_ffn_rows_dbg = 0;  // timing experiments only (results are wrong when set)
-int g_ffn_rows_nw = 0;
-int g_ffn_rows_mb = 1;  // 0 = heuristic; 8 / 12 / 16 waves per workgroup
+int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
+int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
+int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
 
-bool ffn_rows_supported(int D, int F) { return D == 72 && F % 32 == 0 && F >= 64; }
+bool ffn_rows_supported(int D, int F) { return D == 72 && F % 64 == 0 && F >= 64; }
 // large M: where k_ffn_ln ran its 64-row persistent form
-bool ffn_rows_selected(int M, int D, int F) { return g_ffn_rows && ffn_rows_supported(D, F) && cdiv(M, 64) >= 512; }
+bool ffn_rows_selected(int M, int D, int F) {
+  return g_ffn_rows && ffn_rows_supported(D, F) && (g_ffn_rows == 2 || cdiv(M, 64) >= 512);
+}
 
-template <int D, int MB, int NW, int NSLOT>
+template <int D, int NW, int CPS, int NSLOT>
 static hipError_t launch_rows_cfg(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
                                   unsigned long long* stamp) {
-  const int R = 16 * MB * NW;
+  const int R = 32 * NW;
   const int ntiles = cdiv(M, R);
   const int grid = ntiles < num_cus() ? ntiles : num_cus();
-  hipLaunchKernelGGL((k_ffn_rows<D, MB, NW, NSLOT>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, g_ffn_rows_dbg, stamp);
+  hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
   return hipGetLastError();
 }
 
@@ -428,12 +433,28 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
                            unsigned long long* stamp) {
   if (M <= 0) return hipSuccess;
   if (!ffn_rows_supported(D, F) || w.ring == nullptr) return hipErrorInvalidValue;
-  const int cfg = g_ffn_rows_nw * 10 + g_ffn_rows_mb;
-  switch (cfg) {
-    case 82: return launch_rows_cfg<72, 2, 8, 3>(X, w, Y, M, F, s, stamp);
-    case 121: return launch_rows_cfg<72, 1, 12, 4>(X, w, Y, M, F, s, stamp);
-    case 161: return launch_rows_cfg<72, 1, 16, 3>(X, w, Y, M, F, s, stamp);
-    default: return launch_rows_cfg<72, 1, 8, 4>(X, w, Y, M, F, s, stamp);
+  // Waves per workgroup: a tile is 32 NW rows and every CU walks ceil(tiles / CUs) of them at NW / 4 waves per SIMD.
+  // Pick the NW with the least estimated time = passes x waves per SIMD / measured main-loop efficiency
+  // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.83 / 0.90 / 0.93 of the matrix pipe at 1 / 2 / 3 waves per
+  // SIMD); ties go to more waves (the weights are then streamed fewer times).  ffd_tune "ffn_rows_nw" forces it.
+  int nw = g_ffn_rows_nw;
+  if (nw != 4 && nw != 8 && nw != 12) {
+    const double eff[3] = {0.83, 0.90, 0.93};
+    double best = 0.0;
+    for (int i = 2; i >= 0; --i) {
+      const int cand = 4 * (i + 1);
+      const double t = (double)cdiv(cdiv(M, 32 * cand), num_cus()) * (i + 1) / eff[i];
+      if (best == 0.0 || t < best * 0.999) best = t, nw = cand;
+    }
+  }
+  const int cps = g_ffn_rows_cps == 1 ? 1 : 2;  // 32-unit chunks per ring slot = per barrier (ffd_tune "ffn_rows_cps")
+  switch (nw * 10 + cps) {
+    case 41: return launch_rows_cfg<72, 4, 1, 4>(X, w, Y, M, F, s, stamp);
+    case 42: return launch_rows_cfg<72, 4, 2, 3>(X, w, Y, M, F, s, stamp);
+    case 81: return launch_rows_cfg<72, 8, 1, 4>(X, w, Y, M, F, s, stamp);
+    case 82: return launch_rows_cfg<72, 8, 2, 3>(X, w, Y, M, F, s, stamp);
+    case 121: return launch_rows_cfg<72, 12, 1, 4>(X, w, Y, M, F, s, stamp);
+    default: return launch_rows_cfg<72, 12, 2, 3>(X, w, Y, M, F, s, stamp);
   }
 }
 

@@ -106,10 +106,8 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
                                 const float* beta, float* Y, int M, int D, hipStream_t s);
 // Fused FFN: Y = LN2(X + W2 relu(W1 X + b1) + b2)
 // stamp != nullptr (diagnostics): per-workgroup (shader-clock, 100 MHz real-time) deltas around the main loop
-// tile_ctr: two zero-initialised device ints owned by the context (dynamic tile hand-out of the persistent form; the
-// kernel re-arms them); nullptr = static partition
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
-                         unsigned long long* stamp = nullptr, int* tile_ctr = nullptr);
+                         unsigned long long* stamp = nullptr);
 int ffn_tile_rows(int M);
 // Row-owning FFN with a CU-shared LDS weight ring (ffd_ffn_rows.hip): the large-M form
 bool ffn_rows_supported(int D, int F);
@@ -118,7 +116,7 @@ size_t ffn_ring_floats(int D, int F);
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
 hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                            unsigned long long* stamp = nullptr);
-extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_mb, g_ffn_rows_dbg;
+extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps;
 // Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
 // workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
 int small_path_splits(int M, int D, int F);
@@ -143,10 +141,7 @@ hipError_t launch_ffn_ln_split(const float* X, const LayerWeights& w, float* Y, 
                                unsigned long long* stamp = nullptr);
 extern int g_ffn_mb_override;
 extern int g_ffn_rem;
-extern int g_ffn_stagger;
 extern int g_ffn_persist;
-extern int g_ffn_dynamic;
-extern int g_ffn_prio;
 extern int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
 size_t attn_pack_floats(int D, int H, int hpw, int q_only);

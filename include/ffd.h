@@ -288,8 +288,13 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
 /* Process-wide tuning knobs for experiments and for the test suite's kernel variants (results stay within the
  * parity tolerance, only the kernel choice / tiling changes):
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
- *   "ffn_persist" = 1 | 0 | n                  fused FFN at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
- *   "ffn_dynamic" = 1 | 0                      persistent FFN: tiles handed out by a device counter, or a static partition;
+ *   "reset" (value ignored)                    every knob below back to its default;
+ *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72): row-owning waves + CU-shared LDS weight ring
+ *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
+ *                                              every M where the small- / mid-batch forms are off (test suite);
+ *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave);
+ *   "ffn_rows_cps" = 0 | 2 | 1                 32-unit chunks per ring slot (= per barrier) of k_ffn_rows (default 2);
+ *   "ffn_persist" = 1 | 0 | n                  k_ffn_ln at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
  *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
  *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most
  *                                              workgroups the split form is used for (0 = heuristic);
@@ -303,9 +308,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *                                              a wave's shared x rows through LDS or per-lane loads;
  *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
  *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
- *   "ffn_prio" = 1 | 0                         fused FFN: raised wave priority outside the main loop;
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
- *   "ffn_stagger" = -1 (heuristic) | n         start delay (x64 cycles) of the odd wave slot in the FFN;
  *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
  *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);

@@ -246,11 +246,22 @@ def test_encoders_reference_tests(ffd, golden):
 
 
 # -------------------------------------------------------------- models -----
-@pytest.fixture(params=["auto", "large", "unfused", "split"])
+@pytest.fixture(autouse=True)
+def _tune_defaults():
+    """ffd_tune is process-wide state: every test starts from, and leaves behind, the defaults."""
+    yield
+    if torch.cuda.is_available():
+        from fastfourierdiffusion_amd import _native as N
+
+        assert N.lib().ffd_tune(b"reset", 0) == 0
+
+
+@pytest.fixture(params=["auto", "large", "rows", "unfused", "split"])
 def variant(request, ffd):
     """Kernel variants that must all meet the same parity bar: default heuristics (at these small batches: the
     q-/key-split fused attention kernel and the F-split out-proj + FFN pair), "large" (the kernels the heuristics pick
-    at large batches, forced: one workgroup per head (pair), k_linear_res_ln + k_ffn_ln) and the two-kernel
+    at large batches, forced: one workgroup per head (pair), k_linear_res_ln + k_ffn_ln), "rows" (the same with the
+    large-batch FFN of d_model 72 forced at every size: k_ffn_rows, row-owning waves under the LDS weight ring) and the two-kernel
     projection / attention fallback ("unfused"); and "split": the opt-in FFN on the bf16 matrix cores as a three-part,
     six-term split (fp32-equivalent, csrc/ffd_ffn_split.hip), which has to pass the same goldens at the same tolerance."""
     from fastfourierdiffusion_amd import _native as N
@@ -260,14 +271,13 @@ def variant(request, ffd):
         assert lib.ffd_tune(b"ffn_split", 1) == 0
     if request.param == "unfused":
         assert lib.ffd_tune(b"attn_fused", 0) == 0
-    if request.param == "large":
+    if request.param in ("large", "rows"):
         assert lib.ffd_tune(b"attn_small", 0) == 0
         assert lib.ffd_tune(b"small_path", 0) == 0
+    if request.param == "rows":
+        assert lib.ffd_tune(b"mid_path", 0) == 0 and lib.ffd_tune(b"ffn_rows", 2) == 0
     yield request.param
-    lib.ffd_tune(b"ffn_split", 0)
-    lib.ffd_tune(b"attn_fused", 1)
-    lib.ffd_tune(b"attn_small", 1)
-    lib.ffd_tune(b"small_path", 1)
+    lib.ffd_tune(b"reset", 0)
 
 
 @pytest.mark.parametrize("c", cases.MODEL_CASES, ids=lambda c: c["name"])
@@ -431,6 +441,66 @@ def test_lstm_full_batch_properties(ffd):
     t = torch.full((2,), 0.45, dtype=torch.float32)
     ref = O.lstm_score_forward(x[40:42], t, sd, c["NL"])
     assert rel_err(out[40:42], ref) < TOL_SCORE
+
+
+def test_lstm_production_batch_selection(ffd):
+    """BASELINE configs[3] shape at B = 2048: the batch the production selection hands to k_lstm_mfma (B >= 1792; no
+    ffd_tune here).  Sample independence against small-batch evaluations (k_lstm_layer) for three picks, a two-sample
+    slice against the oracle, and the kernel class bench.py would report."""
+    import ctypes as C
+
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    B = 2048
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444)))
+    out = m(batch_of(x.cuda(), 0.45)).cpu()
+    assert torch.isfinite(out).all()
+    ctx = m._ctx()
+    fl, by = C.c_double(), C.c_double()
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, B, 0, C.byref(fl), C.byref(by)) == b"k_lstm_mfma"
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_layer"
+    for b in (0, 1023, 2047):
+        one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
+        assert rel_err(out[b:b + 1], one) < 2e-6, b
+    t = torch.full((2,), 0.45, dtype=torch.float32)
+    ref = O.lstm_score_forward(x[1500:1502], t, sd, c["NL"])
+    assert rel_err(out[1500:1502], ref) < TOL_SCORE
+
+
+@pytest.mark.parametrize("name", ["ecg", "nasa_lstm"])
+def test_checkpoint_to_device_to_forward_golden(ffd, golden, tmp_path, name):
+    """cmd/sample.py:68-77 / cmd/benchmark_cache.py:141-150: load_from_checkpoint(...) -> .cuda() -> forward.  The
+    golden case's state_dict is written as a Lightning-style file (hyper_parameters with the pickled scheduler object +
+    state_dict + the cached_backbone.* copies enable_caching leaves in a trained checkpoint), read back with
+    weights_only=True, moved to the device and evaluated against the reference's scores for that state_dict (g5).
+    (No real trained checkpoint exists in the reference tree: the file is synthesised, the expected output is the
+    unmodified reference's.)"""
+    from fastfourierdiffusion_amd.models.score_models import LSTMScoreModule, ScoreModule
+    from fastfourierdiffusion_amd.schedulers.sde import VPScheduler
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+    assert c["sde"] == "vp"
+    sch = VPScheduler(fourier_noise_scaling=c["fourier"], **c["sde_kwargs"])
+    sd = dict(make_sd(c))
+    hp = dict(n_channels=c["C"], max_len=c["L"], noise_scheduler=sch, fourier_noise_scaling=c["fourier"],
+              d_model=c["d"], num_layers=c["NL"], num_training_steps=1000, lr_max=1e-3, likelihood_weighting=False)
+    cls = LSTMScoreModule
+    if c["kind"] != "lstm":
+        cls = ScoreModule
+        hp["n_head"] = c["H"]
+        sd["cached_backbone.0.linear1.weight"] = torch.zeros(3)
+    path = tmp_path / "epoch=7-val_loss=0.12.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": hp, "pytorch-lightning_version": "2.1.0", "epoch": 7}, path)
+    m = cls.load_from_checkpoint(checkpoint_path=str(path), weights_only=False)  # (always read with weights_only=True)
+    m.noise_scheduler.set_noise_scaling(c["L"])
+    m = m.cuda().eval()
+    g = golden["g5_models"]
+    x = torch.from_numpy(next(synthetic.noise_stream((c["B"], c["L"], c["C"]), 1, c["xseed"]))).cuda()
+    for tv in c["t_values"]:
+        assert rel_err(m(batch_of(x, tv)).cpu(), g[f"{name}_score_t{tv}"]) < TOL_SCORE, (name, tv)
 
 
 def test_errors_are_loud(ffd):
@@ -964,7 +1034,7 @@ def test_kernel_timing_and_work_accounting(ffd):
     assert counts[N.K_EMBED] == 3 and counts[N.K_LSTM_REC] == 0
     assert counts[N.K_SDE] == 3  # the unembed may be fused into it
     fl, by = C.c_double(), C.c_double()
-    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_ln"
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_rows"
     assert fl.value == 4.0 * 512 * L * d * F  # 56.47 GFLOP at the ECG bench shape
     # the sampling loop unembeds inside the step kernel: hidden row + x in, x out
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)).startswith(b"k_unembed_mfma")
@@ -1159,11 +1229,12 @@ def test_config5_shard_cached_modes_at_size(ffd, B):
         assert rel_err(big[j][1], crf) < TOL_SCORE, j
 
 
-def test_ffn_persistent_grid_equals_one_workgroup_per_tile(ffd):
-    """The fused FFN at large M walks its tiles with a persistent grid (two workgroups per CU, next X tile fetched by
-    LDS-DMA under the current main loop).  Tile-to-workgroup assignment must not show in the result: the ECG B = 512
-    score (1 496 FFN tiles over 512 workgroups) is bit-identical with one workgroup per tile and with a 2x grid, and a
-    ragged last tile (M = 513 * 187 = 95 931 rows, 59 rows in the last tile) stays finite and independent."""
+def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
+    """The FFN at large M is k_ffn_rows: row-owning waves (32 rows each, whole hidden dimension) under a CU-shared LDS
+    weight ring.  Which wave of which workgroup owns a row, and how many chunks a ring slot holds, must not show in the
+    result: the ECG B = 512 score is bit-identical for 4 / 8 / 12 waves per workgroup (tiles of 128 / 256 / 384 rows,
+    3 / 2 / 1 tiles per CU) and for one or two chunks per slot; a ragged last tile (M = 513 * 187 rows) stays finite
+    and independent; the F-split kernel it replaces (k_ffn_ln, other summation order) agrees to rounding."""
     from fastfourierdiffusion_amd import _native as N
 
     c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
@@ -1171,27 +1242,39 @@ def test_ffn_persistent_grid_equals_one_workgroup_per_tile(ffd):
     lib = N.lib()
     x = torch.from_numpy(next(synthetic.noise_stream((513, c["L"], c["C"]), 1, 909))).cuda()
     outs = {}
-    try:
-        for p in (1, 0, 2):
-            assert lib.ffd_tune(b"ffn_persist", p) == 0
-            outs[p] = m(batch_of(x[:512].contiguous(), 0.3))
-        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[1], outs[2])
-        assert lib.ffd_tune(b"ffn_persist", 1) == 0
-        # tiles handed out by the device counter (default) vs the static round-robin partition; twice in a row: the
-        # last workgroup of a launch re-arms the counters
-        assert lib.ffd_tune(b"ffn_dynamic", 0) == 0
-        static = m(batch_of(x[:512].contiguous(), 0.3))
-        assert lib.ffd_tune(b"ffn_dynamic", 1) == 0
-        again = m(batch_of(x[:512].contiguous(), 0.3))
-        assert torch.equal(outs[1], static) and torch.equal(outs[1], again)
-        ragged = m(batch_of(x, 0.3))
-    finally:
-        lib.ffd_tune(b"ffn_persist", 1)
-        lib.ffd_tune(b"ffn_dynamic", 1)
+    for nw, cps in ((0, 0), (4, 1), (4, 2), (8, 1), (8, 2), (12, 1), (12, 2)):
+        assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", cps) == 0
+        outs[(nw, cps)] = m(batch_of(x[:512].contiguous(), 0.3))
+    ref = outs[(0, 0)]
+    for k, v in outs.items():
+        assert torch.equal(ref, v), k
+    assert lib.ffd_tune(b"reset", 0) == 0
+    ragged = m(batch_of(x, 0.3))
     assert torch.isfinite(ragged).all()
-    assert rel_err(ragged[:512].cpu(), outs[1].cpu()) < 2e-6
-    one = m(batch_of(x[512:513].contiguous(), 0.3))
+    assert torch.equal(ragged[:512], ref)  # a row's result does not depend on the batch around it
+    one = m(batch_of(x[512:513].contiguous(), 0.3))  # (B = 1 runs the small-batch kernels: other summation order)
     assert rel_err(ragged[512:513].cpu(), one.cpu()) < 2e-6
+    assert lib.ffd_tune(b"ffn_rows", 0) == 0
+    old = m(batch_of(x[:512].contiguous(), 0.3))
+    assert rel_err(old.cpu(), ref.cpu()) < 2e-6
+
+
+def test_ffn_ln_persistent_grid_equals_one_workgroup_per_tile(ffd):
+    """k_ffn_ln (the F-split workgroup; large M of every d_model without a k_ffn_rows instance, selected here with
+    ffd_tune "ffn_rows" = 0) walks its tiles with a persistent grid: bit-identical with one workgroup per tile and with
+    a 2x grid."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((512, c["L"], c["C"]), 1, 909))).cuda()
+    assert lib.ffd_tune(b"ffn_rows", 0) == 0
+    outs = {}
+    for p in (1, 0, 2):
+        assert lib.ffd_tune(b"ffn_persist", p) == 0
+        outs[p] = m(batch_of(x, 0.3))
+    assert torch.equal(outs[1], outs[0]) and torch.equal(outs[1], outs[2])
 
 
 def test_shard_invariance_with_and_without_batch_statistics(ffd):

@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx()
 s = N.current_stream_ptr(dev)
-assert ctx.lib.ffd_tune(b"ffn_mb", 4) == 0 and ctx.lib.ffd_tune(b"ffn_stagger", 0) == 0
+assert ctx.lib.ffd_tune(b"ffn_rows", 0) == 0 and ctx.lib.ffd_tune(b"ffn_mb", 4) == 0  # (k_ffn_ln, the F-split form)
 out = []
 for B in (87, 174, 512):  # 16 269 rows = 255 tiles; 32 538 rows = 509 tiles; the bench shape
     ghz, us = C.c_double(), C.c_double()

@@ -13,6 +13,9 @@ dev = torch.device("cuda", 0)
 model, sch, sd = bench.build_model(dev, sys.argv[1] if len(sys.argv) > 1 else "ecg")
 ctx = model._ctx(); lib = ctx.lib
 L, Cn = model.max_len, model.n_channels
+for kv in os.environ.get("FFD_TUNE", "").split(","):
+    if kv:
+        assert lib.ffd_tune(kv.split("=")[0].encode(), int(kv.split("=")[1])) == 0, kv
 out = {}
 for B in (512, 513):
     x = torch.from_numpy(next(synthetic.noise_stream((B, L, Cn), 1, 77))).to(dev)

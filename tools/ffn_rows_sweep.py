@@ -7,8 +7,8 @@ import torch
 import bench
 from fastfourierdiffusion_amd import _native as N
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-cfgs = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "8:1,8:2,12:1,16:1").split(",")]
-dbgs = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "0").split(",")]
+cfgs = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "4:1,4:2,8:1,8:2,12:1,12:2").split(",")]
+dbgs = [0]
 dev = torch.device("cuda", 0)
 model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx(); lib = ctx.lib
@@ -16,7 +16,7 @@ s = N.current_stream_ptr(dev)
 out = []
 for nw, mb in cfgs:
   for dbg in dbgs:
-    assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_mb", mb) == 0 and lib.ffd_tune(b"ffn_rows_dbg", dbg) == 0
+    assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", mb) == 0
     ms = C.c_float(); best = 1e9
     for _ in range(3):
         N.check(lib.ffd_bench_ffn(ctx.handle, B, 30, C.byref(ms), s), ctx.handle)
@@ -27,9 +27,9 @@ for nw, mb in cfgs:
     N.check(lib.ffd_probe_ffn_clock(ctx.handle, B, 0.5, C.byref(ghz), C.byref(us), raw, cap, C.byref(n), s), ctx.handle)
     r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value].astype(np.float64)
     loop_us = float(np.median((r[:, 4] - r[:, 3]) * 0.01))
-    mf = (68 * 32 + (0 if dbg & 1 else 16 * 8)) * 64 * (nw // 4) * mb  # MFMA issue cycles per SIMD and tile
+    mf = (68 * 64 + (0 if dbg & 1 else 32 * 8)) * 64 * (nw // 4)  # MFMA issue cycles per SIMD and tile (32 rows per wave)
     out.append({"nw": nw, "mb": mb, "dbg": dbg, "kernel_us": round(best, 1), "ghz": round(ghz.value, 3),
                 "tile_loop_us": round(loop_us, 1), "loop_eff": round(mf / (loop_us * ghz.value * 1e3), 3),
                 "exit_us_max": round(float(((r[:, 6] - r[:, 2].min()) * 0.01).max()), 1)})
-lib.ffd_tune(b"ffn_rows_dbg", 0)
+
 print(json.dumps(out))

@@ -1,6 +1,6 @@
 """Timeline of ONE launch of the fused FFN at the bench shape from in-kernel 100 MHz timestamps (ffd_probe_ffn_clock):
 when workgroups enter, how long prologue / main loop / epilogue of their first tile take, when they exit.
-tools/ffn_timeline.py [B] [persist]"""
+tools/ffn_timeline.py [B] [ffn_rows] [persist]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,15 +8,16 @@ import torch
 import bench
 from fastfourierdiffusion_amd import _native as N
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-persist = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-dynamic = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 1: k_ffn_rows (default), 0: k_ffn_ln
+persist = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 dev = torch.device("cuda", 0)
 model, sch, _ = bench.build_model(dev, "ecg")
 ctx = model._ctx()
 s = N.current_stream_ptr(dev)
-assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0 and ctx.lib.ffd_tune(b"ffn_dynamic", dynamic) == 0
-if os.environ.get("FFN_PRIO"):
-    assert ctx.lib.ffd_tune(b"ffn_prio", int(os.environ["FFN_PRIO"])) == 0
+assert ctx.lib.ffd_tune(b"ffn_persist", persist) == 0 and ctx.lib.ffd_tune(b"ffn_rows", rows) == 0
+for kv in os.environ.get("FFD_TUNE", "").split(","):
+    if kv:
+        assert ctx.lib.ffd_tune(kv.split("=")[0].encode(), int(kv.split("=")[1])) == 0, kv
 if os.environ.get("FFN_SPLIT") == "1":  # the opt-in bf16x3-split kernel (its packs are made by a first forward)
     from fastfourierdiffusion_amd.utils.dataclasses import DiffusableBatch
     assert ctx.lib.ffd_tune(b"ffn_split", 1) == 0
@@ -33,7 +34,7 @@ r[:, 7] = (ru[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
 t0 = r[:, 2].min()
 q = lambda a: [round(float(v), 2) for v in np.percentile(a, [0, 10, 50, 90, 100])]
 tk = 0.01  # us per tick
-out = {"B": B, "persist": persist, "dynamic": dynamic, "workgroups": int(n.value), "shader_clock_ghz": ghz.value,
+out = {"B": B, "ffn_rows": rows, "persist": persist, "workgroups": int(n.value), "shader_clock_ghz": ghz.value,
        "tiles_per_workgroup": q(r[:, 7]),
        "entry_us": q((r[:, 2] - t0) * tk), "exit_us": q((r[:, 6] - t0) * tk),
        "first_prologue_us": q((r[:, 3] - r[:, 2]) * tk), "first_main_loop_us": q((r[:, 4] - r[:, 3]) * tk),
