@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument("--cache", action="store_true", help="time the E2-CRF cached path (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cache-ratio / harness side measurements")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the compact lines for the other BASELINE configs and the API-level end-to-end timing")
     ap.add_argument("--ablation", action="store_true",
                     help="also run the reference harness's ablation grid (cmd/benchmark_cache.py:274-422) at B=1")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ffd_tune (experiments)")
@@ -112,14 +114,44 @@ def self_launch(args, argv) -> int:
     if args.launch_plan:
         print(json.dumps({"n_gpus": args.gpus, "ranks": plan}))
         return 0
+    if args.gpus > 1 and any(k in os.environ for k in ("ROCPROFILER_LIBRARY", "ROCP_TOOL_LIB", "ROCPROFV3_PRELOAD")) or \
+            (args.gpus > 1 and "rocprof" in os.environ.get("LD_PRELOAD", "")):
+        log("bench.py launcher: a profiler preload is active; profile with --gpus 1 (the preload initialises the GPU in "
+            "this parent, which must stay a pure launcher)")
+        return 2
     procs = []
     for p in plan:
         env = dict(os.environ)
         env.update(p["env"])
         procs.append(subprocess.Popen(p["cmd"], env=env, stdout=subprocess.PIPE if p["rank"] == 0 else subprocess.DEVNULL,
                                       text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
+    # Poll every rank: the first failure ends the run (the others would sit in init_process_group / a barrier until
+    # the c10d timeout); rank 0's stdout is drained by a thread so that a full pipe cannot block it.
+    import threading
+
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * len(procs)
+    failed = False
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if not failed and any(c not in (None, 0) for c in codes):
+            failed = True
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            deadline = time.time() + 10.0
+            while time.time() < deadline and any(p.poll() is None for p in procs):
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    reader.join(timeout=5.0)
+    out0 = buf[0] if buf else ""
     line = None
     for ln in (out0 or "").splitlines():
         if ln.startswith("{"):
@@ -260,6 +292,74 @@ def roofline_entry(lib, ctx, N, cls, B, cache_hit, traffic_tab, key):
             "launches_timed": cnt.value}
 
 
+def measure_other(device, workload, B, steps, warmup, use_cache):
+    """Compact line for a non-headline BASELINE config in the default run: value, ms/step and the dominant kernel's
+    roofline fraction (HIP-event pairs on the launch stream), same method as the headline."""
+    import torch
+
+    from fastfourierdiffusion_amd import _native as N
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    model, sch, _ = build_model(device, workload)
+    n_total = 1000
+    sch.set_timesteps(n_total)
+    ts_c = (C.c_float * n_total)(*sch.timesteps.tolist())
+    step_size = float(sch.step_size)
+    sampler = DiffusionSampler(model, B, use_cache=use_cache, cache_kwargs={}, rng="philox", seed=42)
+    stream = N.current_stream_ptr(device)
+    if use_cache:
+        model.cache.reset()
+    Xw = sampler.sample_prior(B)
+    run_steps(model, Xw, ts_c, n_total, step_size, 0, warmup, use_cache, stream, 0)
+    if use_cache:
+        model.cache.reset()
+    X = sampler.sample_prior(B)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    run_steps(model, X, ts_c, n_total, step_size, 0, steps, use_cache, stream, 0)
+    torch.cuda.synchronize(device)
+    sec = (time.perf_counter() - t0) / steps
+    assert torch.isfinite(X).all()
+    ctx = model._ctx()
+    lib = ctx.lib
+    is_lstm = workload == "nasa_lstm"
+    n_ev = min(steps, 3)
+    N.check(lib.ffd_kernel_timing_begin(ctx.handle, 0xFF, n_ev * (3 * model.num_layers + 3)), ctx.handle, "timing_begin")
+    run_steps(model, X, ts_c, n_total, step_size, steps, n_ev, use_cache, stream, 0)
+    N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "timing_end")
+    order = [N.K_LSTM_REC, N.K_LSTM_GATES] if is_lstm else [N.K_FFN, N.K_ATTN, N.K_OUTPROJ]
+    lines = [r for r in (roofline_entry(lib, ctx, N, c, B, use_cache and not is_lstm, {}, "") for c in order) if r]
+    res = {"workload": WORKLOADS[workload], "batch": B, "cache": use_cache, "steps_timed": steps, "warmup": warmup,
+           "value": B / (1000.0 * sec), "unit": "samples/s", "ms_per_step": sec * 1e3,
+           "roofline": {k: lines[0][k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_launch")} if lines else None,
+           "roofline_kernels": [{k: r[k] for k in ("kernel", "bound", "frac", "ms_per_launch")} for r in lines[1:]]}
+    del model, sampler, X, Xw
+    torch.cuda.empty_cache()
+    return res
+
+
+def api_e2e(device, B, rng):
+    """SURVEY 8(d)'s metric through the drop-in API: wall time of DiffusionSampler(model, B).sample(B, 1000) (prior
+    draw, 1000 steps, the copy to the host the reference's sample() ends with) + idft, device-synchronised."""
+    import torch
+
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+    from fastfourierdiffusion_amd.utils.fourier import idft
+
+    model, sch, _ = build_model(device, "ecg")
+    sampler = DiffusionSampler(model, B, rng=rng, seed=42)
+    sampler.sample(num_samples=B, num_diffusion_steps=20)  # warm-up (workspace, time-embedding table)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    x = sampler.sample(num_samples=B, num_diffusion_steps=1000)
+    xt = idft(x)
+    torch.cuda.synchronize(device)
+    sec = time.perf_counter() - t0
+    assert torch.isfinite(xt).all() and tuple(xt.shape) == (B, model.max_len, model.n_channels)
+    return {"rng": rng, "seconds": sec, "samples_per_s": B / sec, "num_samples": B, "num_diffusion_steps": 1000,
+            "includes": "prior draw + 1000 steps + host copy of the samples + idft"}
+
+
 def main() -> None:
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -389,7 +489,9 @@ def main() -> None:
                 "ffd_kernel_timing_begin")
         run_steps(model, X, ts_c, n_total, step_size, 1, n_ev_steps, use_cache, stream, offset)
         N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "ffd_kernel_timing_end")
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
         traffic_tab = json.load(open(tpath)) if os.path.exists(tpath) else {}
         key = f"{args.workload}:{B}" + (":cache" if use_cache else "")
         order = ([N.K_LSTM_REC, N.K_LSTM_GATES] if is_lstm else [N.K_FFN, N.K_ATTN, N.K_OUTPROJ]) + \
@@ -398,7 +500,7 @@ def main() -> None:
         if lines:
             out["roofline"] = lines[0]  # the dominant kernel of this workload
             out["roofline"]["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC passes "
-                                               "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), profiles/r02_traffic.json")
+                                               "(FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), " + os.path.relpath(tpath, ROOT))
             out["roofline_kernels"] = lines[1:]
         if not is_lstm:
             iso = C.c_float()
@@ -470,15 +572,44 @@ def main() -> None:
                   "cache_hit_ratio": r_on["cache_stats"].get("cache_hit_ratio"),
                   "reference_published": "17.70 s / 15.78 s for 20 samples x 100 steps on Apple mps = 1.13 samples/s, "
                                          "ratio 1.12 (BASELINE.md section 1)"}
+            # The contract ("cache-on / cache-off ratio within 5 % of the reference's") is read against the reference's
+            # published ACCELERATOR ratio (mps, 1.12): like for like.  The reference's CPU ratio is data beside it: the
+            # unmodified reference timed in the build container (tools/time_reference_cpu.py, committed) is < 1 there.
+            hb["contract"] = {"reference_ratio": 1.12, "reference_ratio_source": "notebooks/ablation_cache_test.ipynb:277-278 "
+                              "(15.78 s vs 17.70 s, Apple mps, B=1, 20 x 100 steps)", "gpu_ratio": hb["off_over_on"],
+                              "gpu_over_reference": hb["off_over_on"] / 1.12,
+                              "within_5_percent": abs(hb["off_over_on"] / 1.12 - 1.0) <= 0.05}
+            rpath = os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json")
+            if os.path.exists(rpath):
+                rt = json.load(open(rpath))
+                hb["reference_cpu_timing"] = {
+                    "file": "profiles/r03_reference_cpu_timing.json", "threads": rt["threads"],
+                    "num_samples": rt["num_samples"], "num_diffusion_steps": rt["num_diffusion_steps"],
+                    "reference_off_over_on_per_rep": rt["harness_b1"]["reference"]["off_over_on_per_rep"],
+                    "reference_off_over_on_median": rt["harness_b1"]["reference"]["off_over_on_median"],
+                    "oracle_off_over_on_median": rt["harness_b1"]["oracle"]["off_over_on_median"],
+                    "reference_ms_per_step_off": rt["harness_b1"]["reference"]["ms_per_step_off_median"],
+                    "note": "the unmodified reference, build container CPU (not this box); measured, not a target"}
             if not args.no_cpu_baseline:
-                hb["cpu_oracle"] = cpu_harness_b1(sd, L, Cn, NLy, model.n_head, 2, nd)
-                hb["ratio_vs_cpu_ratio"] = hb["off_over_on"] / hb["cpu_oracle"]["off_over_on"]
+                hb["cpu_oracle"] = cpu_harness_b1(sd, L, Cn, NLy, model.n_head, ns, nd)
             out["harness_b1"] = hb
             if args.ablation:
                 gmodel, _, _ = build_model(device, "ecg")
                 rows = run_cache_benchmark(gmodel, num_samples=ns, num_diffusion_steps=nd)
                 gmodel.disable_caching()
                 out["ablation"] = [{k: v for k, v in r.items()} for r in rows]
+        if args.workload == "ecg" and world == 1 and not use_cache and not args.ffn_split and not args.no_other_workloads:
+            # the other BASELINE configs, so that the driver's record carries them (configs[4] per-GPU shard, configs[3]
+            # at the large-batch and at SURVEY's stated batch) and the metric through the Python API
+            del X
+            torch.cuda.empty_cache()
+            out["other_workloads"] = [
+                measure_other(device, "syn512", 8192, 3, 1, True),
+                measure_other(device, "nasa_lstm", 8192, 20, 2, False),
+                measure_other(device, "nasa_lstm", 512, 20, 5, False),
+            ]
+            out["api_e2e"] = [api_e2e(device, B, "philox"), api_e2e(device, B, "torch")]
+            out["api_e2e_over_value"] = out["api_e2e"][0]["samples_per_s"] / value
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (a bounded ~25 s CPU sample)
             out["cpu_baseline"] = cpu_baseline(sd, L, Cn, model.num_layers, model.n_head,
                                                "lstm" if is_lstm else "transformer")

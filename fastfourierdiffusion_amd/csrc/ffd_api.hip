@@ -124,6 +124,20 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
   return FFD_OK;
 }
 
+// Replace a workspace buffer by a larger one: the old allocation is released after the stream has drained (workspaces
+// grow a handful of times; without this every growth kept the old buffer until ffd_destroy -- 3.6 GB for the q/k/v
+// regions at B = 8192, L = 512).
+static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats) {
+  float* old = *p;
+  if (old) {
+    (void)hipDeviceSynchronize();
+    auto it = std::find(ctx->owned.begin(), ctx->owned.end(), (void*)old);
+    if (it != ctx->owned.end()) ctx->owned.erase(it);
+    (void)hipFree(old);
+  }
+  return dev_alloc(ctx, p, nfloats);
+}
+
 static int g_fuse_tail = 1;
 
 // HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
@@ -563,18 +577,17 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   const ffd_model_desc& m = ctx->desc;
   const size_t M = (size_t)B * m.max_len, d = m.d_model;
   HIPCHECK(hipSetDevice(ctx->device));
-  // (old buffers stay owned until destroy; workspaces only grow a handful of times)
   int rc;
-  if ((rc = dev_alloc(ctx, &ctx->h0, M * d))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->score, M * m.n_channels))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->temb_b, (size_t)B * d))) return rc;
+  if ((rc = dev_regrow(ctx, &ctx->h0, M * d))) return rc;
+  if ((rc = dev_regrow(ctx, &ctx->score, M * m.n_channels))) return rc;
+  if ((rc = dev_regrow(ctx, &ctx->temb_b, (size_t)B * d))) return rc;
   if (m.kind == FFD_MODEL_MLP) {
-    if ((rc = dev_alloc(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
-    if ((rc = dev_alloc(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
+    if ((rc = dev_regrow(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
+    if ((rc = dev_regrow(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
     ctx->qkv_floats = (size_t)B * m.dim_feedforward;
   } else if (m.kind == FFD_MODEL_TRANSFORMER) {
-    if ((rc = dev_alloc(ctx, &ctx->h1, M * d))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->attn, M * d))) return rc;
+    if ((rc = dev_regrow(ctx, &ctx->h1, M * d))) return rc;
+    if ((rc = dev_regrow(ctx, &ctx->attn, M * d))) return rc;
   }
   // (the head-major q/k/v regions of the two-kernel attention fallback and the LSTM gate pre-activations are
   //  allocated on first use by ensure_qkv: the default paths never touch them -- 3.6 GB at B = 8192, L = 512)
@@ -584,7 +597,7 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
 
 static int ensure_qkv(ffd_ctx* ctx, size_t floats) {
   if (floats <= ctx->qkv_floats) return FFD_OK;
-  int rc = dev_alloc(ctx, &ctx->qkv, floats);
+  int rc = dev_regrow(ctx, &ctx->qkv, floats);
   if (rc) return rc;
   ctx->qkv_floats = floats;
   return FFD_OK;
@@ -704,7 +717,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       // small M: out-proj + LN1 recomputed per F split, FFN partials + a deterministic reduce / LN2 launch
       const size_t need = small_path_partial_floats(M, d, ns);
       if (need > ctx->ffn_part_floats) {
-        if (int rc = dev_alloc(ctx, &ctx->ffn_part, need)) return rc;
+        if (int rc = dev_regrow(ctx, &ctx->ffn_part, need)) return rc;
         ctx->ffn_part_floats = need;
       }
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
@@ -714,7 +727,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       if (nm) {  // mid-size M: 64-row tiles x F slices, partial tiles + the reduce / LN2 launch
         const size_t need = small_path_partial_floats(cdiv(M, 64) * 64, d, nm);
         if (need > ctx->ffn_part_floats) {
-          if (int rc = dev_alloc(ctx, &ctx->ffn_part, need)) return rc;
+          if (int rc = dev_regrow(ctx, &ctx->ffn_part, need)) return rc;
           ctx->ffn_part_floats = need;
         }
         TIMED(FFD_K_FFN, launch_ffn_mid(alt, w, ctx->ffn_part, cur, M, d, F, nm, s));
@@ -1094,8 +1107,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   const int d = m.d_model;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->fresca_on && B > ctx->fwork_B) {
-    if ((rc = dev_alloc(ctx, &ctx->score2, (size_t)B * m.max_len * m.n_channels))) return rc;
-    if ((rc = dev_alloc(ctx, &ctx->fwork, (size_t)B * m.n_channels * (m.max_len / 2 + 1) + 4))) return rc;
+    if ((rc = dev_regrow(ctx, &ctx->score2, (size_t)B * m.max_len * m.n_channels))) return rc;
+    if ((rc = dev_regrow(ctx, &ctx->fwork, (size_t)B * m.n_channels * (m.max_len / 2 + 1) + 4))) return rc;
     ctx->fwork_B = B;
   }
   // All time embeddings of the trajectory in one launch: t is shared by the batch
@@ -1105,8 +1118,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
       ctx->temb_epoch != ctx->weight_epoch) {
     HIPCHECK(hipStreamSynchronize(s));
     if (n_steps > ctx->temb_cap) {
-      if ((rc = dev_alloc(ctx, &ctx->temb_tab, (size_t)n_steps * d))) return rc;
-      if ((rc = dev_alloc(ctx, &ctx->ts_dev, (size_t)n_steps))) return rc;
+      if ((rc = dev_regrow(ctx, &ctx->temb_tab, (size_t)n_steps * d))) return rc;
+      if ((rc = dev_regrow(ctx, &ctx->ts_dev, (size_t)n_steps))) return rc;
       ctx->temb_cap = n_steps;
     }
     ctx->ts_host.assign(timesteps, timesteps + n_steps);
@@ -1122,6 +1135,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   // (B, L, C) round trip less per step).  FreSca needs the whole score (FFT along L).
   const bool fuse_tail = g_fuse_tail && !ctx->fresca_on && m.kind != FFD_MODEL_MLP &&
                          unembed_sde_supported(m.n_channels, d) && (m.n_channels % 4 != 0 || elem_off % 4 == 0) &&
+                         (m.n_channels % 4 != 0 || reinterpret_cast<uintptr_t>(x) % 16 == 0) &&  // float4 x rows
                          (!z_inject || m.n_channels % 4 != 0 ||  // float4 reads of the injected noise only when C % 4 == 0
                           (reinterpret_cast<uintptr_t>(z_inject) % 16 == 0 && slab % 4 == 0));
   for (int j = 0; j < n_run; ++j) {

@@ -21,7 +21,11 @@ same, sharded or not (they are properties of the reference's algorithm, reproduc
 batch / per shard): the E2-CRF tables come from the batch's element 0 (caching.py:326-328), and
 FreSca's default ``energy`` cutoff is derived from ``|rfft(score)|.mean(dim=(0, 2))`` over the
 local batch (fresca.py:150-158).  Without the cache and with FreSca off or on its ``spatial``
-cutoff a sharded philox run equals the unsharded one (tests/test_gpu_parity.py).
+cutoff a sharded philox run reproduces the unsharded one: the same noise bit for bit, the samples to fp32 rounding
+(a few 1e-7 relative per score evaluation; the contract the tests hold is 1e-5 of the max-norm over a trajectory) --
+not bit for bit, because the kernels a batch size selects differ in summation order (the F-split small-batch FFN pair,
+the key-split attention, the 32-row-per-wave large-batch FFN, the batch-tiled LSTM recurrence; csrc/ffd_small.hip,
+ffd_ffn_rows.hip), and a shard may fall into another regime than the whole batch (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 

@@ -3,7 +3,8 @@
 Sampling is embarrassingly parallel over the batch axis (no cross-sample operator in
 ScoreModule.forward, the SDE step or idft), so an N-GPU node is N independent shards:
 weights replicated (12.8 MB), contiguous sample ranges per rank, Philox noise keyed by
-*global* sample index so results do not depend on N.  There is no data-path collective;
+*global* sample index so the noise does not depend on N (the samples then agree to fp32 rounding,
+not bit for bit: the shard size selects the kernels, see sampling/sampler.py).  There is no data-path collective;
 torch.distributed (RCCL on GPUs, gloo in CPU tests) only carries the barrier and the
 max-over-ranks of elapsed time.  With the E2-CRF cache each shard behaves as an
 independent reference run (its own step-0 table from its own element 0); the same

@@ -1305,6 +1305,28 @@ def test_shard_invariance_with_and_without_batch_statistics(ffd):
 
 
 @pytest.mark.gpu
+def test_shards_in_other_kernel_regimes_agree_to_rounding(ffd):
+    """A shard can fall into another kernel regime than the whole batch: the ECG batch of 192 samples runs
+    k_ffn_rows and one workgroup per head pair; its shards of 48 run the F-sliced mid-batch FFN and shards of 2 the
+    F-split small-batch pair and the key-split attention.  Same Philox noise (keyed by global element index), samples
+    equal to fp32 rounding -- the statement sampler.py / sharding.py make -- not bit for bit."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    B, N = 192, 6
+
+    def run(bs, off):
+        return DiffusionSampler(m, bs, rng="philox", seed=5, sample_offset=off).sample(bs, N)
+
+    full = run(B, 0)
+    quarters = torch.cat([run(48, o) for o in range(0, B, 48)])
+    assert rel_err(quarters, full) < TOL_TRAJ
+    for o in (0, 94, 190):
+        assert rel_err(run(2, o), full[o:o + 2]) < TOL_TRAJ, o
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B", [1, 2, 3, 4, 8, 16, 32, 64, 96])
 def test_small_batch_split_ffn_matches_large_batch_kernels(ffd, B):
     """Small M (the benchmark_cache.py harness's batch of one): out-proj + LN1 + FFN + LN2 run as an F-split pair of
