@@ -185,7 +185,7 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
-    g_attn_hpw = 0, g_attn_qg = 0, g_attn_pv = 1, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
+    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
     g_lstm_mfma_s = 0, g_fuse_tail = 1;
     return FFD_OK;
   }
@@ -267,11 +267,6 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "attn_qg")) {
     if (value < 0 || value > 3) return FFD_ERR_INVALID;
     g_attn_qg = value;
-    return FFD_OK;
-  }
-  if (!strcmp(key, "attn_pv")) {  // P.V of the two-head attention kernel: 0 VALU, 1 dims 0..3 on the 4x4x1 MFMA, 2 all dims
-    if (value < 0 || value > 3) return FFD_ERR_INVALID;
-    g_attn_pv = value;
     return FFD_OK;
   }
   if (!strcmp(key, "attn_hpw")) {

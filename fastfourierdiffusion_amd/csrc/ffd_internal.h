@@ -157,7 +157,6 @@ hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q
                                 const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
                                 int n_own, hipStream_t s);
 extern int g_attn_qg;
-extern int g_attn_pv;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]
 // laid out (B, H, L, hd) -- each (sample, head) slice contiguous, the layout of the K/V tables.

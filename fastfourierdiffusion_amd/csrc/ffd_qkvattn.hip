@@ -26,17 +26,6 @@ namespace ffd {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// acc += p.lo * v  /  acc += p.hi * v  with the scalar broadcast done by the instruction's operand select (no v_mov to
-// build a {p, p} pair): p is a pair of adjacent accumulator registers of the S^T tile.
-__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 p, f32x2 v, f32x2 acc) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "v"(v));
-  return acc;
-}
-__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 p, f32x2 v, f32x2 acc) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "v"(v));
-  return acc;
-}
-
 // ---- weight pack ---------------------------------------------------------------------------------
 // awp[h][ct][step4][lane][4]: the B operand of k-step (4*step4 + i) for lane (n = lane & 15, q = lane >> 4):
 //   full 16-chunks j < D/16 : k = 16 j + 4 q + i          (step4 = j)
@@ -516,7 +505,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 // staged once in LDS and read as the MFMA B operand from there.  Two heads = 4 waves, one per SIMD: a 6-wave
 // workgroup (3 heads) leaves the CU with a single resident workgroup (two of its waves land on SIMDs 0 and 1,
 // so a second one never fits at 3 waves per SIMD) and was slower.
-template <int D, int HD, int HPW, int QG, int NCT, int PV>
+template <int D, int HD, int HPW, int QG, int NCT>
 __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
@@ -534,14 +523,6 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   constexpr int NW = 2 * HPW;           // waves per workgroup
   constexpr int MAXT = 3;               // token tiles per wave: Lp <= 192 -> 12 tiles over >= 4 waves
   constexpr float T = 64.0f;  // scores (log2 domain) may sit this far from the reference before it is refreshed
-  // P.V (PV): 0 = packed fp32 VALU FMAs (p broadcast over the head dims); 1 = head dims 0..3 on v_mfma_f32_4x4x1_16b_f32
-  // with the S^T accumulator register as the B operand (lane = query, block = 4 queries of one lane half, k = that
-  // half's key of register r) and V[key][4 m + i] as A, the remaining dims on the VALU: the exp2 / row sums and the
-  // P.V FMAs no longer queue on one pipe; 2 = every head dim on the 4x4x1 form.
-  constexpr int NM = (PV == 0 || PV == 3) ? 0 : (PV == 2 ? (HD + 3) / 4 : 1);
-  constexpr int EV0 = 4 * NM;                                             // first head dim on the VALU
-  constexpr int NVP = NM == 0 ? HP : (HD > EV0 ? (HD - EV0 + 1) / 2 : 0);  // packed pairs on the VALU
-  constexpr int NMA = NM > 0 ? NM : 1, NVA = NVP > 0 ? NVP : 1;
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int b, hg;
@@ -712,26 +693,15 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
-  struct VFrag {
-    float a[NMA];    // 4x4x1 A operands: V[key][4 m + (lane & 3)]
-    f32x2 v[NVA];    // VALU pairs: V[key][EV0 + 2 e], V[key][EV0 + 2 e + 1]
-  };
-  auto load_v = [&](int r, int kbase, VFrag& dst) {
+  auto load_v = [&](int r, int kbase, f32x2(&dst)[4]) {
     const float* vr = vs + (size_t)(kbase + (r & 3) + 8 * (r >> 2)) * 8;
-#pragma unroll
-    for (int mm = 0; mm < NM; ++mm) dst.a[mm] = vr[4 * mm + (lane & 3)];
-    if constexpr (NM == 0) {
-      const float4 v0 = *reinterpret_cast<const float4*>(vr);
-      dst.v[0] = f32x2{v0.x, v0.y};
-      if (NVP > 1) dst.v[NVP > 1 ? 1 : 0] = f32x2{v0.z, v0.w};
-      if constexpr (HD > 4) {
-        const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
-        if (NVP > 2) dst.v[NVP > 2 ? 2 : 0] = f32x2{v1.x, v1.y};
-        if (NVP > 3) dst.v[NVP > 3 ? 3 : 0] = f32x2{v1.z, v1.w};
-      }
+    const float4 v0 = *reinterpret_cast<const float4*>(vr);
+    dst[0] = f32x2{v0.x, v0.y}, dst[1] = f32x2{v0.z, v0.w};
+    if (HD > 4) {
+      const float4 v1 = *reinterpret_cast<const float4*>(vr + 4);
+      dst[2] = f32x2{v1.x, v1.y}, dst[3] = f32x2{v1.z, v1.w};
     } else {
-#pragma unroll
-      for (int e = 0; e < NVP; ++e) dst.v[e] = *reinterpret_cast<const f32x2*>(vr + EV0 + 2 * e);
+      dst[2] = f32x2{0.f, 0.f}, dst[3] = f32x2{0.f, 0.f};
     }
   };
   const int QT = KT;
@@ -741,8 +711,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     bool acc_empty[QG];
 #pragma unroll
     for (int g = 0; g < QG; ++g) acc_empty[g] = true;
-    f32x2 lsum[QG], acc[QG][NVA];
-    f32x4 yo[QG][NMA];
+    f32x2 lsum[QG], acc[QG][HP];
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       const int qtile = (qt0 + g < QT) ? qt0 + g : QT - 1;
@@ -755,9 +724,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       qn2[g] = nrm[KT + qtile];
       lsum[g] = f32x2{0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < NVA; ++e) acc[g][e] = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int mm = 0; mm < NMA; ++mm) yo[g][mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
     }
 #pragma unroll 1
     for (int t = 0; t < KT; ++t) {
@@ -781,7 +748,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         sc[g] = z;
       }
       const int kbase = 32 * t + 4 * half;
-      VFrag vb[PF];
+      f32x2 vb[PF][4];
 #pragma unroll
       for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
       __builtin_amdgcn_sched_barrier(0);
@@ -816,9 +783,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
             const float corr = __builtin_amdgcn_exp2f(-delta);
             lsum[g] *= corr;
 #pragma unroll
-            for (int e = 0; e < NVP; ++e) acc[g][e] *= corr;
-#pragma unroll
-            for (int mm = 0; mm < NM; ++mm) yo[g][mm] *= corr;
+            for (int e = 0; e < HP; ++e) acc[g][e] *= corr;
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) sc[g][r] -= delta;
@@ -837,22 +802,14 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const VFrag vv = vb[r % PF];
+        f32x2 vv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
+          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
 #pragma unroll
-          for (int mm = 0; mm < NM; ++mm)
-            yo[g][mm] = __builtin_amdgcn_mfma_f32_4x4x1f32(vv.a[mm], sc[g][r], yo[g][mm], 0, 0, 0);
-          if constexpr (PV == 3) {
-            const f32x2 pp = f32x2{sc[g][r & ~1], sc[g][r | 1]};
-#pragma unroll
-            for (int e = 0; e < NVP; ++e)
-              acc[g][e] = (r & 1) ? pk_fma_hi(pp, vv.v[e], acc[g][e]) : pk_fma_lo(pp, vv.v[e], acc[g][e]);
-          } else {
-            const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
-#pragma unroll
-            for (int e = 0; e < NVP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv.v[e], acc[g][e]);
-          }
+          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
         }
         if (r + PF < 16) {
           load_v(r + PF, kbase, vb[r % PF]);
@@ -866,22 +823,13 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       l += __shfl_xor(l, 32);
       const float inv = 1.0f / l;
       const int q = 32 * (qt0 + g) + l31;
-      float o[8];
+      float o[2 * HP];
 #pragma unroll
-      for (int mm = 0; mm < NM; ++mm)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float a0 = yo[g][mm][i];  // the two lane halves summed over their own keys
-          a0 += __shfl_xor(a0, 32);
-          o[4 * mm + i] = a0 * inv;
-        }
-#pragma unroll
-      for (int e = 0; e < NVP; ++e) {
+      for (int e = 0; e < HP; ++e) {
         float a0 = acc[g][e].x, a1 = acc[g][e].y;
         a0 += __shfl_xor(a0, 32);
         a1 += __shfl_xor(a1, 32);
-        if (EV0 + 2 * e < 8) o[EV0 + 2 * e] = a0 * inv;
-        if (EV0 + 2 * e + 1 < 8) o[EV0 + 2 * e + 1] = a1 * inv;
+        o[2 * e] = a0 * inv, o[2 * e + 1] = a1 * inv;
       }
       if (half == 0 && q < L && qt0 + g < QT) {
         float* orow = out + ((size_t)b * L + q) * D + h * HD;
@@ -892,28 +840,18 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   }
 }
 
-template <int D, int HD, int HPW, int QG, int NCT, int PV>
-static hipError_t launch_mh_pv(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
+template <int D, int HD, int HPW, int QG, int NCT>
+static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
                               float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
   constexpr int KST = (HD + 1) / 2;
   constexpr int S4 = (D + 15) / 16;
   const int KT = (L + 31) / 32;
   const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2 * KT) * sizeof(float);
-  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT, PV>;
+  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
   if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
   hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
                      n_own, q_only);
   return hipGetLastError();
-}
-
-int g_attn_pv = 1;  // P.V of the two-head kernel: 0 VALU, 1 head dims 0..3 on the 4x4x1 MFMA, 2 all of them (ffd_tune "attn_pv")
-template <int D, int HD, int HPW, int QG, int NCT>
-static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
-                              float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
-  if (g_attn_pv == 0) return launch_mh_pv<D, HD, HPW, QG, NCT, 0>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, s);
-  if (g_attn_pv == 2) return launch_mh_pv<D, HD, HPW, QG, NCT, 2>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, s);
-  if (g_attn_pv == 3) return launch_mh_pv<D, HD, HPW, QG, NCT, 3>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, s);
-  return launch_mh_pv<D, HD, HPW, QG, NCT, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, s);
 }
 
 // 2 heads per workgroup, 2 waves per head: L <= 192 (<= 3 q-tiles per wave, 12 token tiles over 4 waves)
