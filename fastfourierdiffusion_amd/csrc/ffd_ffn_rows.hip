@@ -33,20 +33,29 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // ---- ring pack: [F/32 chunks][SGC groups][64 lanes][4], groups in the order the waves consume them ---------------
 // MFMA 32x32x2 operands: A lane l = A[i = l & 31][k = l >> 5], B lane l = B[k = l >> 5][j = l & 31],
 //                        C/D lane l reg r = D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31]
-//   groups 0 .. NQ1-1   W1 stream of chunk p, item idx = 4 g + j = k-step s:   W1[32 p + (lane & 31)][2 s + (lane >> 5)]
+//   groups 0 .. NQ1-1   W1 stream of chunk p, item idx = 4 g + j = k-step s:   W1[32 p + (lane & 31)][kperm(s, lane >> 5)]
+//                       kperm: the k pair of step s is (c, c + 4) with c = 32 (s / 16) + 8 ((s % 16) / 4) + s % 4 -- the
+//                       two lane halves of register s of a 32x32 accumulator tile that holds the row (ring_kperm), so
+//                       that X rows loaded (or computed) in accumulator layout ARE the B operands, no lane movement
 //   4 CT groups         item idx: r = idx / CT, ct = idx % CT:   W2[32 ct + (lane & 31)][32 p + f_r + 4 (lane >> 5)]
 //   4 NG groups         (4x4x1 A operands) item idx: r = idx / NG, g = idx % NG:
 //                                                        W2[32 CT + 4 g + (lane & 3)][32 p + f_r + 4 (lane >> 5)]
 //   last group          lanes 0..7: b1[32 p + 4 lane + j]
 constexpr __host__ __device__ int ring_ct(int D) { return D / 32; }
 constexpr __host__ __device__ int ring_ng(int D) { return (D % 32) / 4; }
-constexpr __host__ __device__ int ring_nq1(int D) { return cdiv(D / 2, 4); }
+constexpr __host__ __device__ int ring_ks2(int D) { return 16 * ring_ct(D) + 4 * ((ring_ng(D) + 1) / 2); }  // k pairs of GEMM1
+constexpr __host__ __device__ int ring_nq1(int D) { return cdiv(ring_ks2(D), 4); }
+// column of X that lane half `half` supplies to k-step s (>= D: none, the operand is zero)
+constexpr __host__ __device__ int ring_kperm(int D, int s, int half) {
+  return s < 16 * ring_ct(D) ? 32 * (s / 16) + 8 * ((s % 16) / 4) + 4 * half + s % 4
+                             : 32 * ring_ct(D) + 4 * (2 * ((s - 16 * ring_ct(D)) / 4) + half) + (s - 16 * ring_ct(D)) % 4;
+}
 constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nq1(D) + 4 * (ring_ct(D) + ring_ng(D)) + 1; }
 size_t ffn_ring_floats(int D, int F) { return (size_t)(F / 32) * ring_chunk_groups(D) * 256; }
 
 __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __restrict__ b1,
                                 const float* __restrict__ W2, float* __restrict__ out, int D, int F) {
-  const int KS2 = D / 2, CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D), SG = ring_chunk_groups(D);
+  const int KS2 = ring_ks2(D), CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D), SG = ring_chunk_groups(D);
   const size_t total = (size_t)(F / 32) * SG * 256;
   for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(o & 3), lane = (int)((o >> 2) & 63);
@@ -55,7 +64,8 @@ __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __res
     float v = 0.f;
     if (g < NQ1) {
       const int s = 4 * g + j;
-      if (s < KS2) v = W1[(size_t)(32 * p + (lane & 31)) * D + 2 * s + half];
+      const int kcol = s < KS2 ? ring_kperm(D, s, half) : D;
+      if (kcol < 32 * CT + 4 * NG) v = W1[(size_t)(32 * p + (lane & 31)) * D + kcol];
     } else if (g < NQ1 + 4 * CT) {
       const int idx = 4 * (g - NQ1) + j, r = idx / CT, ct = idx % CT;
       v = W2[(size_t)(32 * ct + (lane & 31)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
@@ -97,7 +107,7 @@ __device__ __forceinline__ float f4e(const float4& q, int j) { return j == 0 ? q
 
 template <int D, int NW, int CPS, int NSLOT>
 struct FfnRowsCfg {
-  static constexpr int KS2 = D / 2;
+  static constexpr int KS2 = ring_ks2(D);
   static constexpr int CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D);
   static constexpr int SGC = ring_chunk_groups(D);           // 1 KiB groups per chunk (the last one: bias)
   static constexpr int NFC = SGC - 1;                        // fragment groups of a chunk
@@ -117,7 +127,7 @@ struct FfnRowsCfg {
 };
 
 template <int D, int NW, int CPS, int NSLOT>
-__global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
+__global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
                                                              const float* __restrict__ b2, const float* __restrict__ gam,
                                                              const float* __restrict__ bet, float* __restrict__ Y, int M,
                                                              int F, unsigned long long* __restrict__ stamp) {
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
   using C = FfnRowsCfg<D, NW, CPS, NSLOT>;
   constexpr int KS2 = C::KS2, CT = C::CT, NG = C::NG, NQ1 = C::NQ1, SGC = C::SGC, NFC = C::NFC, PD = C::PD;
   constexpr int NGA = NG > 0 ? NG : 1, CTA = CT > 0 ? CT : 1;
+  constexpr int NRH = (NG + 1) / 2;  // remainder groups per lane half
   constexpr int R = 32 * NW;
   constexpr int NFS = CPS * NFC;  // fragment groups of a slot
   constexpr int RPG = cdiv(4, CTA);  // accumulator registers (k pairs) one GEMM2 fragment group covers
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LN parameter writes
   __builtin_amdgcn_s_barrier();
 
-  float xf[KS2];
+  float4 xv[CTA][4], xrem[NRH > 0 ? NRH : 1];  // X rows (B operands of GEMM1 and the residual)
   f32x16 yacc[CTA];
   f32x4 yrem[NGA];
   int tile = blockIdx.x, sl = 0;
@@ -188,10 +199,19 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
         st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
         if (st_tiles == 0) st_first_b = st_rt;
       }
+      // The wave's 32 rows in ACCUMULATOR layout: lane (row m, half) holds columns 32 ct + 8 t + 4 half + (0..3) as one
+      // float4 per (ct, t) -- GEMM1's B operands under the pack's k permutation AND the residual of the tile's end.
       const int row = min(tile * R + wave * 32 + m, M - 1);  // rows past M repeat row M-1; they are never stored
       const float* xr = X + (size_t)row * D;
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) xf[s] = xr[2 * s + half];
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xv[ct][t] = *reinterpret_cast<const float4*>(xr + 32 * ct + 8 * t + 4 * half);
+#pragma unroll
+      for (int i = 0; i < NRH; ++i) {  // lane half h holds remainder groups g = 2 i + h
+        xrem[i] = float4{0.f, 0.f, 0.f, 0.f};
+        if (2 * i + half < NG) xrem[i] = *reinterpret_cast<const float4*>(xr + 32 * CT + 4 * (2 * i + half));
+      }
 #pragma unroll
       for (int ct = 0; ct < CTA; ++ct)
 #pragma unroll
@@ -202,7 +222,13 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
       // of the loop body, in EVERY iteration (it cannot know the loads are not re-issued), and those counts also
       // drain the ring's LDS-DMA pieces, which share the counter: the ring then runs one slot deep.
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) asm volatile("" : "+v"(xf[s]));
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          asm volatile("" : "+v"(xv[ct][t].x), "+v"(xv[ct][t].y), "+v"(xv[ct][t].z), "+v"(xv[ct][t].w));
+#pragma unroll
+      for (int i = 0; i < NRH; ++i)
+        asm volatile("" : "+v"(xrem[i].x), "+v"(xrem[i].y), "+v"(xrem[i].z), "+v"(xrem[i].w));
     }
     f32x16 h;
 
@@ -236,7 +262,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
         if (k < NQ1) {
           // ---- GEMM1: H^T chunk (32 hidden x 32 rows), K = D ----
           const int s = 4 * k + j;
-          if (s < KS2) h = mfma32(f4e(w, j), xf[s], h);
+          if (s < KS2) {
+            const float xb = s < 16 * CT ? f4e(xv[s / 16 < CTA ? s / 16 : 0][(s % 16) / 4], s % 4)
+                                         : f4e(xrem[(s - 16 * CT) / 4 < NRH ? (s - 16 * CT) / 4 : 0], (s - 16 * CT) % 4);
+            h = mfma32(f4e(w, j), xb, h);
+          }
         } else if (k < NQ1 + 4 * CT) {
           // ---- GEMM2: Y^T += W2[:, chunk] relu(H^T chunk); accumulator register r is the k pair (f_r, f_r + 4) ----
           const int idx = 4 * (k - NQ1) + j, r = idx / CTA, ct = idx % CTA;
@@ -298,29 +328,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 ? 2 : NW / 4)) void k_ffn_rows(co
         st_acc_rt += rt - st_rt;
         if (st_tiles == 0) st_first_e = rt;
       }
-      // the residual rows again (L2 / MALL hits; re-read here rather than held in 36 registers through the tile)
-      float4 xres[CTA][4], xrem[(NGA + 1) / 2];
-      {
-        const float* xr = X + (size_t)min(tile * R + wave * 32 + m, M - 1) * D;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) xres[ct][t] = *reinterpret_cast<const float4*>(xr + 32 * ct + 8 * t + 4 * half);
-#pragma unroll
-        for (int i = 0; i < (NG + 1) / 2; ++i) {  // lane half h finishes remainder groups g = 2 i + h
-          xrem[i] = float4{0.f, 0.f, 0.f, 0.f};
-          if (2 * i + half < NG) xrem[i] = *reinterpret_cast<const float4*>(xr + 32 * CT + 4 * (2 * i + half));
-        }
-      }
       // yacc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]: four consecutive columns per (ct, t)
-      float4 v[CTA][4], vr[(NGA + 1) / 2];
+      float4 v[CTA][4], vr[NRH > 0 ? NRH : 1];
       float sum = 0.f;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const float4 bq = *reinterpret_cast<const float4*>(&lnp[32 * ct + 8 * t + 4 * half]);
-          const float4 x4 = xres[ct][t];
+          const float4 x4 = xv[ct][t];
           v[ct][t] = float4{x4.x + (yacc[ct][4 * t] + bq.x), x4.y + (yacc[ct][4 * t + 1] + bq.y),
                             x4.z + (yacc[ct][4 * t + 2] + bq.z), x4.w + (yacc[ct][4 * t + 3] + bq.w)};
           sum += (v[ct][t].x + v[ct][t].y) + (v[ct][t].z + v[ct][t].w);
@@ -435,11 +451,11 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
   if (!ffn_rows_supported(D, F) || w.ring == nullptr) return hipErrorInvalidValue;
   // Waves per workgroup: a tile is 32 NW rows and every CU walks ceil(tiles / CUs) of them at NW / 4 waves per SIMD.
   // Pick the NW with the least estimated time = passes x waves per SIMD / measured main-loop efficiency
-  // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.83 / 0.90 / 0.93 of the matrix pipe at 1 / 2 / 3 waves per
+  // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
   // SIMD); ties go to more waves (the weights are then streamed fewer times).  ffd_tune "ffn_rows_nw" forces it.
   int nw = g_ffn_rows_nw;
   if (nw != 4 && nw != 8 && nw != 12) {
-    const double eff[3] = {0.83, 0.90, 0.93};
+    const double eff[3] = {0.85, 0.915, 0.938};
     double best = 0.0;
     for (int i = 2; i >= 0; --i) {
       const int cand = 4 * (i + 1);
