@@ -79,6 +79,8 @@ struct ffd_ctx {
   float tm_ms[FFD_K_COUNT] = {0};
   int tm_n[FFD_K_COUNT] = {0};
   float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
+  int* lstm_prog = nullptr;  // progress words of the LSTM layer wavefront
+  size_t lstm_prog_ints = 0;
   float* ffn_part = nullptr;  // partial Y tiles of the small-M split FFN
   size_t ffn_part_floats = 0;
   // FreSca (sampler-level)
@@ -186,7 +188,7 @@ int ffd_tune(const char* key, int value) {
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
-    g_lstm_mfma_s = 0, g_fuse_tail = 1;
+    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_fuse_tail = 1;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
@@ -253,6 +255,11 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "lstm_mfma_min_batch")) {  // batch from which the batch-tiled MFMA recurrence is used
     if (value < 1) return FFD_ERR_INVALID;
     g_lstm_mfma_min_batch = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_wave")) {  // LSTM layers as a wavefront below the k_lstm_mfma crossover: 1 | 0 | 2 (every batch)
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_lstm_wave = value;
     return FFD_OK;
   }
   if (!strcmp(key, "lstm_mfma_s")) {  // 16-sample tiles per workgroup of that kernel (0 = by batch)
@@ -637,6 +644,17 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
   if (m.kind == FFD_MODEL_LSTM) {
     TIMED(FFD_K_EMBED, launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb,
                                     temb_stride, ctx->h0, B, L, C, d, s));
+    if (lstm_wave_selected(B, d) && m.num_layers <= 64) {  // mid-size batches: the layers as a wavefront (ffd_lstm.hip)
+      const size_t need = (size_t)16 * cdiv(B, 16);
+      if (need > ctx->lstm_prog_ints) {
+        float* pbuf = reinterpret_cast<float*>(ctx->lstm_prog);
+        if (int rc = dev_regrow(ctx, &pbuf, need)) return rc;
+        ctx->lstm_prog = reinterpret_cast<int*>(pbuf), ctx->lstm_prog_ints = need;
+      }
+      const float *wih[64], *whh[64], *bs[64];
+      for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].wih, whh[i] = ctx->lstm[i].whh, bs[i] = ctx->lstm[i].bsum;
+      TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0, wih, whh, bs, m.num_layers, B, L, d, ctx->lstm_prog, s));
+    } else
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];
       if (lstm_mfma_selected(B, d)) {  // batch-tiled MFMA recurrence with the input gates fused
@@ -1289,13 +1307,15 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
         name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
     case FFD_K_LSTM_REC:
-      if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
+      if (ls && lstm_wave_selected(B, m.d_model))  // every layer in one (or a few) launches: x W_ih^T + h W_hh^T
+        name = "k_lstm_wave", fl = m.num_layers * 2.0 * M * 8.0 * d * d, by = m.num_layers * 4.0 * (2.0 * M * d + 8.0 * d * d);
+      else if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
         name = "k_lstm_mfma", fl = 2.0 * M * 8.0 * d * d, by = 4.0 * (2.0 * M * d + 8.0 * d * d);
       else if (ls)  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out
         name = "k_lstm_layer", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * 4.0 * d + 2.0 * M * d + 4.0 * d * d);
       break;
     case FFD_K_LSTM_GATES:
-      if (ls && !lstm_mfma_selected(B, m.d_model))
+      if (ls && !lstm_mfma_selected(B, m.d_model) && !lstm_wave_selected(B, m.d_model))
         name = "k_linear_rm", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * d + M * 4.0 * d + 4.0 * d * d);
       break;
     case FFD_K_SDE:

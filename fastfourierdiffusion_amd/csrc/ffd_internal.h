@@ -177,6 +177,12 @@ bool lstm_mfma_selected(int B, int D);
 extern int g_lstm_mfma_min_batch, g_lstm_mfma_s;
 hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
                             hipStream_t s);
+// batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
+// prog: >= 16 * ceil(B / 16) ints of device scratch (progress words, cleared by the launcher)
+bool lstm_wave_selected(int B, int D);
+extern int g_lstm_wave;
+hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
+                            int B, int L, int D, int* prog, hipStream_t s);
 
 hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,
                         int M, int N, int K, int relu, hipStream_t s);

@@ -397,6 +397,290 @@ int g_lstm_mfma_s = 0;  // 16-sample groups per workgroup: 0 = by batch, 1, 2
 
 bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
 
+// ---------------------------------------------------------------------------
+// Mid-size batches (16-sample tiles fit the chip once per layer group): the layers as a WAVEFRONT in one launch.
+//
+// Layer l at cell step t needs layer l-1 at step t and its own step t-1: the critical path of NL layers is
+// L + (NL - 1) * lag cell steps, not NL * L.  One workgroup per (16-sample tile, layer) runs k_lstm_mfma's cell step
+// (GRP = 1) over the whole sequence, in place on the same (B, L, d) buffer: a row passes through the layers in
+// order, each adding its h_t.  Layer l's workgroup publishes its progress every CHP steps -- rows leave as
+// write-through (sc1) stores, every wave waits for its own stores, the step's workgroup barrier, then ONE lane stores
+// the step count (sc1) -- and layer l+1's workgroup of the same tile polls that word from one wave, joins its own
+// step barrier and reads the rows with sc1 loads (the flag form of MI355X_MICROARCH.md, Workgroup dispatch ...: no
+// fences, nothing depends on which CU or XCD a workgroup landed on).  Lower layers never wait on higher ones and the
+// grid (tiles x layers <= CUs, one workgroup per CU by its LDS) is co-resident; every spin is bounded all the same.
+// ---------------------------------------------------------------------------
+struct LstmWaveArgs {
+  const float* wih[16];
+  const float* whh[16];
+  const float* bsum[16];
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, LstmWaveArgs wa, int n_layers, int n_tiles,
+                                                      int B, int L, int* __restrict__ prog) {
+  // Eight waves, two per SIMD, in two roles (the cell step of k_lstm_mfma split in two):
+  //   waves 0-3 (recurrent): acc = gx_t image; acc += W_hh h_{t-1}^T (W_hh fragments in VGPRs); lane-local cell
+  //                          update; h_t -> LDS.  Only this is on the recurrence's critical path.
+  //   waves 4-7 (input):     gx_{t+1} = b + W_ih x_{t+1}^T (W_ih fragments in VGPRs) -> the other gx image; the tile's
+  //                          rows: global -> registers -> LDS ring three / two steps ahead, x_{t-1} + h_{t-1} back;
+  //                          the wavefront's polling and publishing.
+  // One workgroup barrier per cell step orders h, gx and the x ring for both roles.
+  constexpr int NT = D / 4;          // unit tiles of 4 units x 4 gates == k-steps of 4
+  constexpr int NTW = (NT + 3) / 4;  // tiles per wave (upper bound)
+  constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
+  constexpr int NF4 = 16 * NT;       // float4 slots of a 16-row tile
+  constexpr int NSL = (NF4 + 255) / 256;  // slots per thread (of the 256 input-role threads)
+  constexpr int CHP = 2;             // cell steps between two publications of a layer's progress
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __align__(16) float lds[];
+  float4* gxi = reinterpret_cast<float4*>(lds);       // [2][NT tiles][64 lanes] gate pre-activations, accumulator layout
+  float* hbuf = lds + 2 * NT * 64 * 4;                 // [2][16][HS]  h_{t-1} / h_t
+  float* xbuf = hbuf + 2 * 16 * HS;                    // [3][16][HS]  x_t rows in slot t % 3
+  const int lane = threadIdx.x & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool recur = wave8 < 4;
+  // tile ownership: 18 unit tiles over 4 waves are 5 / 5 / 4 / 4; the input-role wave that shares a SIMD with
+  // recurrent wave w (wave w + 4) takes the mirrored share, so that every SIMD carries 9 tiles per step
+  const int wave = recur ? wave8 : 7 - wave8;
+  const int tg = threadIdx.x & 255;
+  const int layer = blockIdx.x / n_tiles, tile = blockIdx.x - layer * n_tiles;  // (uniform)
+  const float* wsrc = recur ? wa.whh[layer] : wa.wih[layer];
+  const float* bsum = wa.bsum[layer];
+  int* my_prog = prog + layer * n_tiles + tile;
+  const int* up_prog = layer > 0 ? prog + (layer - 1) * n_tiles + tile : nullptr;
+  const int j = lane & 15, q = lane >> 4;
+  const int t0 = wave * (NT / 4) + min(wave, NT % 4);
+  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
+
+  // this role's weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]); row order inside a
+  // 16-row tile is (unit, gate) = (i >> 2, i & 3), see k_lstm_mfma
+  float wf[NTW][NT];
+  f32x4 bias[NTW];
+#pragma unroll
+  for (int tt = 0; tt < NTW; ++tt) {
+    const int T = min(t0 + tt, NT - 1);
+    const bool on = tt < ntw;
+    const size_t row = (size_t)((j & 3) * D + 4 * T + (j >> 2)) * D;
+#pragma unroll
+    for (int s = 0; s < NT; ++s) wf[tt][s] = on ? wsrc[row + 4 * s + q] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 2 * 16 * HS; i += 512) hbuf[i] = 0.f;
+
+  if (recur) {
+    // ------------------------------------------------------------------ recurrent role
+    float c[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) c[tt] = 0.f;
+    __syncthreads();  // A
+    __syncthreads();  // B
+    __syncthreads();  // C: gx_0 is in image 0
+    for (int t = 0; t < L; ++t) {
+      const int cur = t & 1;
+      if (t > 0) __syncthreads();  // h_{t-1} (h image cur) and gx_t (image cur) are complete
+      f32x4 acc[NTW];
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) {
+        const float4 g4 = gxi[(cur * NT + min(t0 + tt, NT - 1)) * 64 + lane];
+        acc[tt] = f32x4{g4.x, g4.y, g4.z, g4.w};
+      }
+      float hb[NT];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) hb[s] = hbuf[(cur * 16 + j) * HS + 4 * s + q];
+#pragma unroll
+      for (int s = 0; s < NT; ++s)
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) acc[tt] = mfma16(wf[tt][s], hb[s], acc[tt]);
+      // cell update, lane-local: (i, f, g, o) = acc[0..3] of unit 4 T + q, sample j
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        if (tt < ntw) {
+          const f32x4 a = acc[tt];
+          const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go2 = sigmoid_fast(a[3]);
+          c[tt] = gf * c[tt] + gi * gg;
+          hbuf[((cur ^ 1) * 16 + j) * HS + 4 * (t0 + tt) + q] = go2 * tanh_fast(c[tt]);
+        }
+    }
+    __syncthreads();  // h_{L-1} complete
+    __syncthreads();  // (the input role's last stores have left)
+    return;
+  }
+
+  // -------------------------------------------------------------------- input role
+  // this thread's float4 slots of the tile's rows: slot f -> row f / NT, columns 4 (f % NT) .. +3; byte offsets
+  // into the (B, L, d) buffer for the raw-buffer (sc1) loads and stores
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(x, 0, (int)((size_t)B * L * D * 4), 0x00020000);
+  const int b0 = tile * 16;
+  unsigned go[NSL];  // byte offset of the slot at t = 0 (sample clamped; stores masked by `ok`)
+  int lo[NSL];
+  bool has[NSL], ok[NSL];
+#pragma unroll
+  for (int k = 0; k < NSL; ++k) {
+    const int f = tg + 256 * k;
+    has[k] = f < NF4;
+    const int r = min(f, NF4 - 1) / NT, c4 = min(f, NF4 - 1) - r * NT;
+    ok[k] = has[k] && b0 + r < B;
+    go[k] = (unsigned)(((size_t)min(b0 + r, B - 1) * L * D + 4 * c4) * 4);
+    lo[k] = r * HS + 4 * c4;
+  }
+  auto gload = [&](int t, float4 (&dst)[NSL]) {
+#pragma unroll
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) {
+        // (whole-vector bit cast: with a per-component __builtin_bit_cast(float, v.x) hipcc / ROCm 7.2 shrinks the load
+        //  to buffer_load_dword and still reads four registers -- tools/probes/probe_buffer_sc1.hip)
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, go[k] + (unsigned)t * (D * 4), 0, 16));  // sc1
+        dst[k] = float4{v[0], v[1], v[2], v[3]};
+      }
+  };
+  auto xput = [&](int par, const float4 (&src)[NSL]) {
+#pragma unroll
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) {
+        float2* d2 = reinterpret_cast<float2*>(xbuf + par * 16 * HS + lo[k]);
+        d2[0] = float2{src[k].x, src[k].y};
+        d2[1] = float2{src[k].z, src[k].w};
+      }
+  };
+  auto out_store = [&](int t, int par, int xs) {  // x_t + h_t -> the buffer (write-through)
+#pragma unroll
+    for (int k = 0; k < NSL; ++k)
+      if (ok[k]) {
+        const float2* h2 = reinterpret_cast<const float2*>(hbuf + par * 16 * HS + lo[k]);
+        const float2* x2 = reinterpret_cast<const float2*>(xbuf + xs * 16 * HS + lo[k]);
+        const float2 a = h2[0], b = h2[1], u = x2[0], v = x2[1];
+        const f32x4 o = f32x4{u.x + a.x, u.y + a.y, v.x + b.x, v.y + b.y};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, go[k] + (unsigned)t * (D * 4), 0, 16);  // sc1
+      }
+  };
+  // wave 4 waits until the layer below has published `need` cell steps (the other waves meet it at the step barrier)
+  int known = layer > 0 ? 0 : L;
+  auto await_rows = [&](int need) {
+    if (wave8 == 4 && known < need) {
+      for (int spin = 0; spin < (1 << 24); ++spin) {
+        known = __hip_atomic_load(up_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (known >= need) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+  };
+  // gx image `img` <- b + W_ih x^T for this wave's tiles, x fragments from ring slot `par`
+  auto input_part = [&](int par, int img) {
+    float xf[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) xf[s] = xbuf[(par * 16 + j) * HS + 4 * s + q];
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias[tt];
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) acc[tt] = mfma16(wf[tt][s], xf[s], acc[tt]);
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+      if (tt < ntw) gxi[(img * NT + t0 + tt) * 64 + lane] = float4{acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]};
+  };
+
+  int nld = 0;  // row-load instructions this wave issues per step (a slot index past the tile issues none)
+#pragma unroll
+  for (int k = 0; k < NSL; ++k) nld += (256 * k + 64 * (wave8 & 3) < NF4) ? 1 : 0;
+  float4 xn[NSL];
+  await_rows(min(3, L));
+  __syncthreads();  // A
+  gload(0, xn);
+  xput(0, xn);
+  if (L > 1) {
+    gload(1, xn);
+    xput(1, xn);
+  }
+  if (L > 2) gload(2, xn);
+  __syncthreads();  // B: ring slots 0, 1 written
+  input_part(0, 0);
+  __syncthreads();  // C
+  int s0 = 0, s1 = 1, s2 = 2;  // ring slots of x_t, x_{t+1}, x_{t+2} (= the slot x_{t-1} occupied)
+  for (int t = 0; t < L; ++t) {
+    const int cur = t & 1;
+    // publication due: rows 0 .. t-2 were stored during earlier iterations; each wave retires its own stores (its
+    // `nld` row loads of step t+2 are younger and may stay in flight), the barrier collects the waves, one lane signs
+    const bool publish = t >= 2 && (t - 1) % CHP == 0;
+    if (t > 0) {
+      if (publish) {
+        if (t + 2 >= L) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nld == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nld == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      await_rows(min(t + 4, L));
+      __syncthreads();  // h_{t-1}, gx_t, x_{t+1} (ring slot s1) complete
+      if (publish && tg == 0) __hip_atomic_store(my_prog, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      out_store(t - 1, cur, s2);  // x_{t-1} + h_{t-1}
+    } else {
+      await_rows(min(4, L));
+    }
+    if (t + 1 < L) input_part(s1, cur ^ 1);  // gx_{t+1}
+    // slot s2 held x_{t-1}: its fragments were read two steps ago and this thread just wrote its rows back
+    if (t + 2 < L) xput(s2, xn);
+    if (t + 3 < L) gload(t + 3, xn);
+    const int r = s0;
+    s0 = s1, s1 = s2, s2 = r;
+  }
+  __syncthreads();  // h_{L-1} complete
+  out_store(L - 1, L & 1, s2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tg == 0) __hip_atomic_store(my_prog, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5 * 16 * (D + 2)) * 4; }
+
+int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
+
+bool lstm_wave_selected(int B, int D) {
+  if (g_lstm_wave == 0 || D % 4 != 0 || D < 16) return false;
+  if (cdiv(B, 16) > num_cus()) return false;  // a 16-sample tile per CU and layer
+  return g_lstm_wave == 2 || !lstm_mfma_selected(B, D);
+}
+
+template <int D>
+static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const float* const* whh, const float* const* bsum,
+                                     int NL, int B, int L, int* prog, hipStream_t s) {
+  constexpr size_t lds = lstm_wave_lds(D);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_wave<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  const int n_tiles = cdiv(B, 16);
+  int per = num_cus() / n_tiles;  // layers per launch: every workgroup of a launch is resident
+  if (per > 16) per = 16;
+  if (per < 1) return hipErrorInvalidValue;
+  for (int l0 = 0; l0 < NL; l0 += per) {
+    const int nl = NL - l0 < per ? NL - l0 : per;
+    LstmWaveArgs wa{};
+    for (int i = 0; i < nl; ++i) wa.wih[i] = wih[l0 + i], wa.whh[i] = whh[l0 + i], wa.bsum[i] = bsum[l0 + i];
+    hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)nl * n_tiles, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_lstm_wave<D>), dim3(nl * n_tiles), dim3(512), lds, s, x, wa, nl, n_tiles, B, L, prog);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
+                            int B, int L, int D, int* prog, hipStream_t s) {
+  if (B <= 0 || NL <= 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (size_t)B * L * D * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+  switch (D) {
+#define X(d) \
+  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, s);
+    X(16) X(24) X(32) X(48) X(60) X(64) X(72)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int D, int GRP>
 static hipError_t launch_lstm_mfma_t(float* x, const float* wih, const float* whh, const float* bsum, int B, int L,
                                      hipStream_t s) {

@@ -311,6 +311,9 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
  *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
  *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
+ *   "lstm_wave" = 1 | 0 | 2                    LSTM below that batch: all layers as a wavefront of (16-sample tile, layer)
+ *                                              workgroups in one launch per layer group (k_lstm_wave), or the per-layer
+ *                                              kernels (0); 2 = at every batch (test suite);
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;

@@ -461,7 +461,7 @@ def test_lstm_production_batch_selection(ffd):
     ctx = m._ctx()
     fl, by = C.c_double(), C.c_double()
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, B, 0, C.byref(fl), C.byref(by)) == b"k_lstm_mfma"
-    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_layer"
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_wave"
     for b in (0, 1023, 2047):
         one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
         assert rel_err(out[b:b + 1], one) < 2e-6, b
@@ -1121,6 +1121,49 @@ def test_fused_unembed_sde_tail_equals_two_kernels(ffd, name):
     for philox in (True, False):
         assert torch.isfinite(res[(1, philox)]).all()
         assert torch.equal(res[(1, philox)], res[(0, philox)]), philox
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["nasa_lstm", "small_lstm", "refunit_lstm"])
+def test_lstm_wavefront_golden(ffd, golden, name):
+    """The LSTM layers as a wavefront of (16-sample tile, layer) workgroups in one launch (k_lstm_wave: the production
+    selection below the k_lstm_mfma crossover, here pinned on with ffd_tune "lstm_wave" = 2) against the reference's
+    scores (g5), and against the per-layer kernels (ffd_tune "lstm_wave" = 0)."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+    m, _ = make_model(ffd, c)
+    g = golden["g5_models"]
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((c["B"], c["L"], c["C"]), 1, c["xseed"]))).cuda()
+    for tv in c["t_values"]:
+        assert lib.ffd_tune(b"lstm_wave", 2) == 0
+        w = m(batch_of(x, tv)).cpu()
+        assert lib.ffd_tune(b"lstm_wave", 0) == 0
+        per_layer = m(batch_of(x, tv)).cpu()
+        assert rel_err(w, g[f"{name}_score_t{tv}"]) < TOL_SCORE, (name, tv)
+        assert rel_err(w, per_layer) < 2e-6, (name, tv)
+
+
+@pytest.mark.gpu
+def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
+    """k_lstm_wave over batch sizes that leave a ragged last tile, one tile, and more tiles than a launch holds with
+    all ten layers (B = 512: 32 tiles -> layers in groups of 8 + 2; B = 1100: 69 tiles -> groups of 3): every sample
+    equals its evaluation in a small batch, a slice equals the oracle."""
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    for B in (1, 37, 512, 1100):
+        x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4500 + B)))
+        out = m(batch_of(x.cuda(), 0.45)).cpu()
+        assert torch.isfinite(out).all()
+        for b in sorted({0, B // 2, B - 1}):
+            lo = min(b, max(0, B - 2))
+            two = m(batch_of(x[lo:lo + 2].cuda(), 0.45)).cpu()
+            assert rel_err(out[b:b + 1], two[b - lo:b - lo + 1]) < 2e-6, (B, b)
+        n = min(2, B)
+        ref = O.lstm_score_forward(x[:n], torch.full((n,), 0.45, dtype=torch.float32), sd, c["NL"])
+        assert rel_err(out[:n], ref) < TOL_SCORE, B
 
 
 @pytest.fixture
