@@ -126,7 +126,7 @@ struct FfnRowsCfg {
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 };
 
-template <int D, int NW, int CPS, int NSLOT>
+template <int D, int NW, int CPS, int NSLOT, int PR>
 __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
                                                              const float* __restrict__ b2, const float* __restrict__ gam,
                                                              const float* __restrict__ bet, float* __restrict__ Y, int M,
@@ -249,6 +249,20 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
     for (int K = 0; K < NFS; ++K) {
       const int c = K / NFC, k = K % NFC;  // chunk of the slot, group of the chunk (compile-time after unrolling)
       const float4 w = f[K];
+      if (PR) {
+        // Descending priority through the barrier interval: a wave ahead of its SIMD's other waves yields to them
+        // (issue arbitration is priority, then age: at equal priority the oldest wave takes every slot it can use and
+        // the youngest runs the last third of the interval alone, at a lone wave's efficiency).
+        constexpr int KB = (CPS - 1) * NFC + NQ1;  // first group after the slot's barrier
+        const int rel = (K - KB + NFS) % NFS;
+        if (rel == 0 || (rel * 4) / NFS != ((rel - 1) * 4) / NFS) {
+          const int lvl = 3 - (rel * 4) / NFS;  // (the builtin wants a literal; the chain folds after unrolling)
+          if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+          else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+          else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+      }
       if (k == 0) {  // the bias is GEMM1's initial accumulator
 #pragma unroll
         for (int t = 0; t < 4; ++t) h[4 * t] = hb[t].x, h[4 * t + 1] = hb[t].y, h[4 * t + 2] = hb[t].z, h[4 * t + 3] = hb[t].w;
@@ -435,13 +449,22 @@ bool ffn_rows_selected(int M, int D, int F) {
   return g_ffn_rows && ffn_rows_supported(D, F) && (g_ffn_rows == 2 || cdiv(M, 64) >= 512);
 }
 
+int g_ffn_rows_prio = 1;  // descending wave priority through a barrier interval (ffd_tune "ffn_rows_prio")
+
 template <int D, int NW, int CPS, int NSLOT>
 static hipError_t launch_rows_cfg(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
                                   unsigned long long* stamp) {
   const int R = 32 * NW;
   const int ntiles = cdiv(M, R);
-  const int grid = ntiles < num_cus() ? ntiles : num_cus();
-  hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
+  // workgroups per CU: as many rings as fit the 160 KB of LDS and 12 waves
+  constexpr int per_cu_lds = (160 * 1024) / (FfnRowsCfg<D, NW, CPS, NSLOT>::LDS_FLOATS * 4);
+  constexpr int per_cu = per_cu_lds < 12 / NW ? per_cu_lds : 12 / NW;
+  const int slots = per_cu * num_cus();
+  const int grid = ntiles < slots ? ntiles : slots;
+  if (g_ffn_rows_prio && NW > 4)
+    hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, 1>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
+  else
+    hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, 0>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
   return hipGetLastError();
 }
 
@@ -454,7 +477,7 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
   // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
   // SIMD); ties go to more waves (the weights are then streamed fewer times).  ffd_tune "ffn_rows_nw" forces it.
   int nw = g_ffn_rows_nw;
-  if (nw != 4 && nw != 8 && nw != 12) {
+  if (nw != 4 && nw != 6 && nw != 8 && nw != 12) {
     const double eff[3] = {0.85, 0.915, 0.938};
     double best = 0.0;
     for (int i = 2; i >= 0; --i) {
@@ -465,6 +488,8 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
   }
   const int cps = g_ffn_rows_cps == 1 ? 1 : 2;  // 32-unit chunks per ring slot = per barrier (ffd_tune "ffn_rows_cps")
   switch (nw * 10 + cps) {
+    case 61:
+    case 62: return launch_rows_cfg<72, 6, 1, 3>(X, w, Y, M, F, s, stamp);  // two workgroups (two rings) per CU
     case 41: return launch_rows_cfg<72, 4, 1, 4>(X, w, Y, M, F, s, stamp);
     case 42: return launch_rows_cfg<72, 4, 2, 3>(X, w, Y, M, F, s, stamp);
     case 81: return launch_rows_cfg<72, 8, 1, 4>(X, w, Y, M, F, s, stamp);

@@ -116,7 +116,7 @@ size_t ffn_ring_floats(int D, int F);
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
 hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                            unsigned long long* stamp = nullptr);
-extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps;
+extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_prio;
 // Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
 // workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
 int small_path_splits(int M, int D, int F);

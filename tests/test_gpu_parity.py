@@ -1275,8 +1275,8 @@ def test_config5_shard_cached_modes_at_size(ffd, B):
 def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     """The FFN at large M is k_ffn_rows: row-owning waves (32 rows each, whole hidden dimension) under a CU-shared LDS
     weight ring.  Which wave of which workgroup owns a row, and how many chunks a ring slot holds, must not show in the
-    result: the ECG B = 512 score is bit-identical for 4 / 8 / 12 waves per workgroup (tiles of 128 / 256 / 384 rows,
-    3 / 2 / 1 tiles per CU) and for one or two chunks per slot; a ragged last tile (M = 513 * 187 rows) stays finite
+    result: the ECG B = 512 score is bit-identical for 4 / 6 / 8 / 12 waves per workgroup (tiles of 128 / 192 / 256 / 384
+    rows; 6 waves = two workgroups with a ring each per CU) and for one or two chunks per slot; a ragged last tile (M = 513 * 187 rows) stays finite
     and independent; the F-split kernel it replaces (k_ffn_ln, other summation order) agrees to rounding."""
     from fastfourierdiffusion_amd import _native as N
 
@@ -1285,7 +1285,7 @@ def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     lib = N.lib()
     x = torch.from_numpy(next(synthetic.noise_stream((513, c["L"], c["C"]), 1, 909))).cuda()
     outs = {}
-    for nw, cps in ((0, 0), (4, 1), (4, 2), (8, 1), (8, 2), (12, 1), (12, 2)):
+    for nw, cps in ((0, 0), (4, 1), (4, 2), (6, 1), (8, 1), (8, 2), (12, 1), (12, 2)):
         assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", cps) == 0
         outs[(nw, cps)] = m(batch_of(x[:512].contiguous(), 0.3))
     ref = outs[(0, 0)]
