@@ -31,6 +31,7 @@ struct LstmLayer {
 struct LayerPacked {
   float *in_wp, *q_wp, *kv_wp, *out_wp, *w1p, *w2p, *w2r;
   float* ring = nullptr;  // weight ring pack of the row-owning FFN
+  float* ring_op = nullptr;  // + its out-projection slot (fused form)
   float *w1s = nullptr, *w2s = nullptr;  // bf16x3 packs of the opt-in split FFN, made on first use
   float *aw_full = nullptr, *aw_q = nullptr;    // per-head packs of the fused in-projection + attention kernel
   float *aw_full2 = nullptr, *aw_q2 = nullptr;  // same, per pair of heads (two-head workgroups)
@@ -186,7 +187,7 @@ int ffd_tune(const char* key, int value) {
   if (!key) return FFD_ERR_INVALID;
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
-    g_ffn_rows_cps = 0, g_ffn_rows_prio = 1, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
+    g_ffn_rows_cps = 0, g_ffn_rows_prio = 1, g_ffn_rows_fuse = 1, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
     g_lstm_mfma_s = 0, g_lstm_wave = 1, g_fuse_tail = 1;
     return FFD_OK;
@@ -241,6 +242,10 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "ffn_rows_cps")) {
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_ffn_rows_cps = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_rows_fuse")) {  // out-projection + LN1 inside k_ffn_rows (1, default) or k_linear_res_ln before it (0)
+    g_ffn_rows_fuse = value ? 1 : 0;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_rows_prio")) {
@@ -508,7 +513,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if ((rc = dev_alloc(ctx, &pk.w2p, w2pack_floats(d, F)))) return rc;
         if ((rc = dev_alloc(ctx, &pk.w2r, w2rem_floats(d, F)))) return rc;
         if (ffn_rows_supported(d, F))
+        {
           if ((rc = dev_alloc(ctx, &pk.ring, ffn_ring_floats(d, F)))) return rc;
+          if ((rc = dev_alloc(ctx, &pk.ring_op, ffn_ring_oproj_floats(d)))) return rc;
+        }
       }
       float* in_w = W(pre + "self_attn.in_proj_weight");
       HIPCHECK(launch_pack_dweight(in_w, pk.in_wp, 3 * d, d, s));
@@ -527,8 +535,10 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(W(pre + "linear1.weight"), pk.w1p, F, d, s));
       HIPCHECK(launch_pack_w2(W(pre + "linear2.weight"), pk.w2p, d, F, s));
       HIPCHECK(launch_pack_w2rem(W(pre + "linear2.weight"), pk.w2r, d, F, s));
-      if (pk.ring)
+      if (pk.ring) {
         HIPCHECK(launch_pack_ffn_ring(W(pre + "linear1.weight"), W(pre + "linear1.bias"), W(pre + "linear2.weight"), pk.ring, d, F, s));
+        HIPCHECK(launch_pack_oproj_ring(W(pre + "self_attn.out_proj.weight"), pk.ring_op, d, s));
+      }
       if (pk.w1s) HIPCHECK(launch_pack_ffn_split(W(pre + "linear1.weight"), W(pre + "linear2.weight"), pk.w1s, pk.w2s, d, F, s));
       LayerWeights& lw = ctx->layers[i];
       lw.in_w = in_w;
@@ -549,6 +559,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       lw.w2p = pk.w2p;
       lw.w2r = pk.w2r;
       lw.ring = pk.ring;
+      lw.ring_op = pk.ring_op;
       lw.w1s = pk.w1s;
       lw.w2s = pk.w2s;
     }
@@ -743,6 +754,12 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
         ctx->ffn_part_floats = need;
       }
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
+    } else if (!split_ffn && !mid_path_splits(M, d, F) && w.ring_op != nullptr && ffn_rows_fused_selected(M, d, F)) {
+      // large M, d_model 72: out-proj + LN1 + FFN + LN2 in one launch (x1 never leaves the CU); the output goes to the
+      // other hidden buffer (rows are read and written by different waves of different tiles: no in-place form)
+      TIMED(FFD_K_FFN, launch_oproj_ffn_rows(ctx->attn, cur, w, alt, M, d, F, s));
+      float* t = cur;
+      cur = alt, alt = t;
     } else {
       TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
       const int nm = split_ffn ? 0 : mid_path_splits(M, d, F);
@@ -1295,6 +1312,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
       else if (tr && mid_path_splits((int)M, m.d_model, m.dim_feedforward))
         name = "k_ffn_part", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
+      else if (tr && ffn_rows_fused_selected((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
+        name = "k_ffn_rows<oproj>", fl = 4.0 * M * d * F + 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
       else if (tr && ffn_rows_selected((int)M, m.d_model, m.dim_feedforward))
         name = "k_ffn_rows", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       else if (tr) name = "k_ffn_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
@@ -1307,7 +1326,9 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       }
       break;
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
-      if (tr && (g_ffn_split || !small_path_splits((int)M, m.d_model, m.dim_feedforward)))
+      if (tr && (g_ffn_split || (!small_path_splits((int)M, m.d_model, m.dim_feedforward) &&
+                                 !(!mid_path_splits((int)M, m.d_model, m.dim_feedforward) &&
+                                   ffn_rows_fused_selected((int)M, m.d_model, m.dim_feedforward)))))
         name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
     case FFD_K_LSTM_REC:
@@ -1356,8 +1377,16 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, (size_t)M * d, 0x9E3779B9u);
   HIPCHECK(hipGetLastError());
+  // (the form the forward pass takes at this size: with the out-projection + LN1 inside it where that is selected)
+  const bool fused = !g_ffn_split && ctx->layers[0].ring_op && !mid_path_splits(M, d, m.dim_feedforward) &&
+                     ffn_rows_fused_selected(M, d, m.dim_feedforward);
+  if (fused) {
+    hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->attn, (size_t)M * d, 0x85EBCA6Bu);
+    HIPCHECK(hipGetLastError());
+  }
   auto run = [&]() -> hipError_t {
-    return launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s);
+    return fused ? launch_oproj_ffn_rows(ctx->attn, ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s)
+                 : launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s);
   };
   for (int i = 0; i < 3; ++i) HIPCHECK(run());
   hipEvent_t e0, e1;
@@ -1392,9 +1421,16 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   const bool split = g_ffn_split && ctx->layers[0].w1s != nullptr;  // (packed by the first forward with ffn_split on)
   if (g_ffn_split && !split) return ctx->fail(FFD_ERR_STATE, "ffn_split: run one forward first (the packs are made on first use)");
   const int nwg = split ? (cdiv(M, 64) < num_cus() ? cdiv(M, 64) : num_cus()) : cdiv(M, ffn_tile_rows(M));  // upper bound of the grid (the persistent form launches fewer)
+  const bool fused = !split && ctx->layers[0].ring_op && !mid_path_splits(M, d, m.dim_feedforward) &&
+                     ffn_rows_fused_selected(M, d, m.dim_feedforward);
+  if (fused) {
+    hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->attn, (size_t)M * d, 0x85EBCA6Bu);
+    HIPCHECK(hipGetLastError());
+  }
   auto launch = [&](unsigned long long* st) {
     return split ? launch_ffn_ln_split(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st)
-                 : launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st);
+           : fused ? launch_oproj_ffn_rows(ctx->attn, ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st)
+                   : launch_ffn_ln(ctx->h1, ctx->layers[0], ctx->h0, M, d, m.dim_feedforward, s, st);
   };
   unsigned long long* stamps = nullptr;
   HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 8 * nwg));

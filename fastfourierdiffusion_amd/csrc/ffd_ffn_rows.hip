@@ -79,28 +79,48 @@ __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __res
   }
 }
 
+// ---- out-projection slot (fused out-proj + LN1 form): [NPM main-tile groups][NPR remainder groups][64 lanes][4] --------
+//   main groups      item idx = 4 g + j: k-step s = idx / CT, column tile ct = idx % CT:  Wo[32 ct + (lane & 31)][kperm(s, lane >> 5)]
+//   remainder groups item idx: s = idx / NG, gq = idx % NG (4x4x1 A operands):   Wo[32 CT + 4 gq + (lane & 3)][kperm(s, lane >> 5)]
+// (the attention rows, loaded in accumulator layout like the FFN's X rows, are the B operands under the same k permutation)
+constexpr __host__ __device__ int oproj_npm(int D) { return cdiv(ring_ks2(D) * ring_ct(D), 4); }
+constexpr __host__ __device__ int oproj_npr(int D) { return cdiv(ring_ks2(D) * ring_ng(D), 4); }
+size_t ffn_ring_oproj_floats(int D) { return (size_t)2 * ring_chunk_groups(D) * 256; }  // one two-chunk slot
+
+__global__ void k_pack_oproj_ring(const float* __restrict__ Wo, float* __restrict__ out, int D) {
+  const int KS2 = ring_ks2(D), CT = ring_ct(D), NG = ring_ng(D), NPM = oproj_npm(D), NPR = oproj_npr(D);
+  const int total = 2 * ring_chunk_groups(D) * 256;
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
+    const int j = o & 3, lane = (o >> 2) & 63, g = o >> 8, half = lane >> 5;
+    float v = 0.f;
+    if (g < NPM) {
+      const int idx = 4 * g + j, s = idx / CT, ct = idx % CT;
+      if (s < KS2) {
+        const int kcol = ring_kperm(D, s, half);
+        if (kcol < D) v = Wo[(size_t)(32 * ct + (lane & 31)) * D + kcol];
+      }
+    } else if (g < NPM + NPR) {
+      const int idx = 4 * (g - NPM) + j, s = idx / NG, gq = idx % NG;
+      if (s < KS2) {
+        const int kcol = ring_kperm(D, s, half);
+        if (kcol < D) v = Wo[(size_t)(32 * CT + 4 * gq + (lane & 3)) * D + kcol];
+      }
+    }
+    out[o] = v;
+  }
+}
+
+hipError_t launch_pack_oproj_ring(const float* Wo, float* out, int D, hipStream_t s) {
+  if (D % 8 != 0 || D < 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pack_oproj_ring, dim3(64), dim3(256), 0, s, Wo, out, D);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F,
                                 hipStream_t s) {
   if (F % 32 != 0 || D % 4 != 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_pack_ffn_ring, dim3(512), dim3(256), 0, s, W1, b1, W2, out, D, F);
   return hipGetLastError();
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_byte, lds_byte + 1024).
-// Issued from inline asm on purpose: for the builtin form hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
-// next ds_read of the same __shared__ array (it cannot tell the ring's slots apart), which drains the ring every slot.
-// The kernel orders DMA and reads itself: counted vmcnt + s_barrier (see the slot barrier below).
-__device__ __forceinline__ void dma_piece(const float* g, unsigned lds_byte) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g)
-               : "memory");  // (m0 is a reserved register: hipcc keeps nothing in it across statements)
-}
-__device__ __forceinline__ unsigned lds_addr(const float* p) {
-  return (unsigned)(unsigned long)((const __attribute__((address_space(3))) float*)p);
 }
 
 __device__ __forceinline__ float f4e(const float4& q, int j) { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
@@ -113,7 +133,7 @@ struct FfnRowsCfg {
   static constexpr int NFC = SGC - 1;                        // fragment groups of a chunk
   static constexpr int SLOT_G = CPS * SGC;
   static constexpr int SLOT_FLOATS = SLOT_G * 256;
-  static constexpr int LNP = 3 * D;                          // b2, gamma, beta
+  static constexpr int LNP = 6 * D;                          // b2, gamma2, beta2; out-proj bias, gamma1, beta1 (fused form)
   static constexpr int LNP_PAD = cdiv(LNP, 4) * 4;
   static constexpr int LDS_FLOATS = NSLOT * SLOT_FLOATS + LNP_PAD;
   static constexpr int NST = 4 * CT + (NG + 1) / 2;          // float4 stores per lane in a tile epilogue (at most)
@@ -124,23 +144,120 @@ struct FfnRowsCfg {
   static_assert((AHEAD - 2) * NPW + NST <= 63 && AHEAD >= 2, "vmcnt range");
   static_assert(NPW <= NFC - NQ1, "one DMA piece per fragment group after the barrier");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
+  // fused out-projection slot
+  static constexpr int NPM = oproj_npm(D), NPR = oproj_npr(D), NFP = NPM + NPR;
 };
 
-template <int D, int NW, int CPS, int NSLOT, int PR>
-__global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ ring,
+// b + residual + LayerNorm of the wave's 32 rows, in registers.  acc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]
+// (four consecutive columns per (ct, t)), rem[g][e] = this lane half's partial sum of column 32 CT + 4 g + e; res / resrem
+// the residual rows in the same layout; p = {bias[D], gamma[D], beta[D]} in LDS.  Returns the normalised rows in
+// v / vr (lane half h owns remainder groups g = 2 i + h).
+template <int D>
+__device__ __forceinline__ void ln_rows(const f32x16* acc, const f32x4* rem, const float4 (*res)[4], const float4* resrem,
+                                        const float* p, int half, float4 (*v)[4], float4* vr) {
+  constexpr int CT = ring_ct(D), NG = ring_ng(D);
+  float sum = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float4 bq = *reinterpret_cast<const float4*>(&p[32 * ct + 8 * t + 4 * half]);
+      const float4 x4 = res[ct][t];
+      v[ct][t] = float4{x4.x + (acc[ct][4 * t] + bq.x), x4.y + (acc[ct][4 * t + 1] + bq.y),
+                        x4.z + (acc[ct][4 * t + 2] + bq.z), x4.w + (acc[ct][4 * t + 3] + bq.w)};
+      sum += (v[ct][t].x + v[ct][t].y) + (v[ct][t].z + v[ct][t].w);
+    }
+  if (NG > 0) {
+    // the two lane halves hold partial sums over their own k values: add them (both halves get the total);
+    // half h then finishes groups g = 2 i + h
+#pragma unroll
+    for (int i = 0; i < (NG + 1) / 2; ++i) {
+      float a[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float t0 = rem[2 * i][e];
+        t0 += __shfl_xor(t0, 32);
+        float t1 = 0.f;
+        if (2 * i + 1 < NG) {
+          t1 = rem[(2 * i + 1 < NG) ? 2 * i + 1 : 0][e];
+          t1 += __shfl_xor(t1, 32);
+        }
+        a[e] = half ? t1 : t0;
+      }
+      vr[i] = float4{0.f, 0.f, 0.f, 0.f};
+      if (2 * i + half < NG) {
+        const float4 bq = *reinterpret_cast<const float4*>(&p[32 * CT + 4 * (2 * i + half)]);
+        const float4 x4 = resrem[i];
+        vr[i] = float4{x4.x + (a[0] + bq.x), x4.y + (a[1] + bq.y), x4.z + (a[2] + bq.z), x4.w + (a[3] + bq.w)};
+        sum += (vr[i].x + vr[i].y) + (vr[i].z + vr[i].w);
+      }
+    }
+  }
+  sum += __shfl_xor(sum, 32);
+  const float mean = sum * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float a = v[ct][t].x - mean, b = v[ct][t].y - mean, c2 = v[ct][t].z - mean, d = v[ct][t].w - mean;
+      ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
+    }
+#pragma unroll
+  for (int i = 0; i < (NG + 1) / 2; ++i)
+    if (2 * i + half < NG) {
+      const float a = vr[i].x - mean, b = vr[i].y - mean, c2 = vr[i].z - mean, d = vr[i].w - mean;
+      ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
+    }
+  ss += __shfl_xor(ss, 32);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c0 = 32 * ct + 8 * t + 4 * half;
+      const float4 g4 = *reinterpret_cast<const float4*>(&p[D + c0]);
+      const float4 e4 = *reinterpret_cast<const float4*>(&p[2 * D + c0]);
+      v[ct][t] = float4{(v[ct][t].x - mean) * rstd * g4.x + e4.x, (v[ct][t].y - mean) * rstd * g4.y + e4.y,
+                        (v[ct][t].z - mean) * rstd * g4.z + e4.z, (v[ct][t].w - mean) * rstd * g4.w + e4.w};
+    }
+#pragma unroll
+  for (int i = 0; i < (NG + 1) / 2; ++i)
+    if (2 * i + half < NG) {
+      const int c0 = 32 * CT + 4 * (2 * i + half);
+      const float4 g4 = *reinterpret_cast<const float4*>(&p[D + c0]);
+      const float4 e4 = *reinterpret_cast<const float4*>(&p[2 * D + c0]);
+      vr[i] = float4{(vr[i].x - mean) * rstd * g4.x + e4.x, (vr[i].y - mean) * rstd * g4.y + e4.y,
+                     (vr[i].z - mean) * rstd * g4.z + e4.z, (vr[i].w - mean) * rstd * g4.w + e4.w};
+    }
+}
+
+// OP (fused form, cached_transformer.py:316-327 in one launch): X is the ATTENTION output and Rin the layer input; a
+// tile starts with one extra ring slot -- the out-projection fragments (`ringp`) -- from which every wave computes
+// x1 = LayerNorm1(Rin + Wo attn + bo) of its 32 rows on the same two MFMA forms; x1 never leaves the registers (it is
+// GEMM1's B operand and LN2's residual).  Without OP, X is x1 itself (k_linear_res_ln wrote it).
+template <int D, int NW, int CPS, int NSLOT, int PR, bool OP>
+__global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ Rin,
+                                                             const float* __restrict__ ring, const float* __restrict__ ringp,
                                                              const float* __restrict__ b2, const float* __restrict__ gam,
-                                                             const float* __restrict__ bet, float* __restrict__ Y, int M,
-                                                             int F, unsigned long long* __restrict__ stamp) {
+                                                             const float* __restrict__ bet, const float* __restrict__ bo,
+                                                             const float* __restrict__ gam1, const float* __restrict__ bet1,
+                                                             float* __restrict__ Y, int M, int F,
+                                                             unsigned long long* stamp) {
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): the record k_ffn_ln writes (8 x u64 per
   // workgroup), to memory nothing else reads
   using C = FfnRowsCfg<D, NW, CPS, NSLOT>;
   constexpr int KS2 = C::KS2, CT = C::CT, NG = C::NG, NQ1 = C::NQ1, SGC = C::SGC, NFC = C::NFC, PD = C::PD;
   constexpr int NGA = NG > 0 ? NG : 1, CTA = CT > 0 ? CT : 1;
   constexpr int NRH = (NG + 1) / 2;  // remainder groups per lane half
+  constexpr int NRA = NRH > 0 ? NRH : 1;
   constexpr int R = 32 * NW;
   constexpr int NFS = CPS * NFC;  // fragment groups of a slot
   constexpr int RPG = cdiv(4, CTA);  // accumulator registers (k pairs) one GEMM2 fragment group covers
+  constexpr int NPM = C::NPM, NFP = C::NFP;
   static_assert(CT == 0 || 4 % CT == 0, "relu placement assumes CT in {1, 2, 4}");
+  static_assert(!OP || (CPS == 2 && C::AHEAD == 2 && NFP + PD <= NFS + PD && NFP <= C::SLOT_G && NG > 0 && CT > 0),
+                "the fused form: two-chunk slots, ring one slot ahead of the barrier");
   __shared__ __align__(16) float lds[C::LDS_FLOATS];
 
   const int lane = threadIdx.x & 63;
@@ -151,39 +268,90 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   const unsigned ring_base = __builtin_amdgcn_readfirstlane(lds_addr(ringl));
 
   const int ntiles = (M + R - 1) / R;
-  const int NSL = F / (32 * CPS);  // slots per tile
+  const int NSL = F / (32 * CPS) + (OP ? 1 : 0);  // slots per tile (fused form: slot 0 = the out-projection)
   const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * NSL;
   if (total == 0) return;  // (uniform over the workgroup)
 
+  auto slot_src = [&](int wslot) -> const float* {  // packed slot `wslot` of a tile's stream
+    return OP ? (wslot == 0 ? ringp : ring + (size_t)(wslot - 1) * C::SLOT_FLOATS) : ring + (size_t)wslot * C::SLOT_FLOATS;
+  };
   auto issue_ring = [&](int wslot, int rslot) {  // packed slot `wslot` of the layer -> ring slot `rslot`
-    const float* src = ring + (size_t)wslot * C::SLOT_FLOATS + lane * 4;
+    const float* src = slot_src(wslot) + lane * 4;
     const unsigned dst = ring_base + (unsigned)rslot * (C::SLOT_FLOATS * 4);
     for (int g = wave; g < C::SLOT_G; g += NW) dma_piece(src + g * 256, dst + g * 1024);
   };
 
-  // ---- prologue: LN parameters, first AHEAD slots ----
-  for (int i = threadIdx.x; i < C::LNP; i += 64 * NW) lnp[i] = i < D ? b2[i] : i < 2 * D ? gam[i - D] : bet[i - 2 * D];
+  float4 xv[CTA][4], xrem[NRA];  // X rows (B operands of GEMM1 and the residual)
+  f32x16 yacc[CTA];
+  f32x4 yrem[NGA];
+  int tile = blockIdx.x;
+  int wnext = C::AHEAD % NSL;  // packed slot the next ring DMA fetches
+  // The wave's 32 rows of `src` in ACCUMULATOR layout: lane (row m, half) holds columns 32 ct + 8 t + 4 half + (0..3) as
+  // one float4 per (ct, t) -- B operands under the pack's k permutation, and residual rows.
+  auto load_rows = [&](const float* src, float4 (*q)[4], float4* qrem) {
+    const int row = min(tile * R + wave * 32 + m, M - 1);  // rows past M repeat row M-1; they are never stored
+    const float* xr = src + (size_t)row * D;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) q[ct][t] = *reinterpret_cast<const float4*>(xr + 32 * ct + 8 * t + 4 * half);
+#pragma unroll
+    for (int i = 0; i < NRH; ++i) {  // lane half h holds remainder groups g = 2 i + h
+      qrem[i] = float4{0.f, 0.f, 0.f, 0.f};
+      if (2 * i + half < NG) qrem[i] = *reinterpret_cast<const float4*>(xr + 32 * CT + 4 * (2 * i + half));
+    }
+  };
+  // Retire loads HERE: left to itself hipcc waits for them with counted vmcnt in front of their first use in the loop
+  // body, in EVERY iteration (it cannot know the loads are not re-issued), and those counts also drain the ring's
+  // LDS-DMA pieces, which share the counter: the ring then runs one slot deep.
+  auto retire_rows = [&](float4 (*q)[4], float4* qrem) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(q[ct][t].x), "+v"(q[ct][t].y), "+v"(q[ct][t].z), "+v"(q[ct][t].w));
+#pragma unroll
+    for (int i = 0; i < NRH; ++i) asm volatile("" : "+v"(qrem[i].x), "+v"(qrem[i].y), "+v"(qrem[i].z), "+v"(qrem[i].w));
+  };
+  auto xb_of = [&](int s) -> float {  // B operand of k-step s
+    return s < 16 * CT ? f4e(xv[s / 16 < CTA ? s / 16 : 0][(s % 16) / 4], s % 4)
+                       : f4e(xrem[(s - 16 * CT) / 4 < NRH ? (s - 16 * CT) / 4 : 0], (s - 16 * CT) % 4);
+  };
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < CTA; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NGA; ++g) yrem[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- prologue: LN parameters, first AHEAD slots; the first tile's rows are requested under the ring fill ----
+  for (int i = threadIdx.x; i < (OP ? 6 : 3) * D; i += 64 * NW)
+    lnp[i] = i < D ? b2[i] : i < 2 * D ? gam[i - D] : i < 3 * D ? bet[i - 2 * D]
+           : i < 4 * D ? bo[i - 3 * D] : i < 5 * D ? gam1[i - 4 * D] : bet1[i - 5 * D];
 #pragma unroll
   for (int j = 0; j < C::AHEAD; ++j)
     if (j < total) issue_ring(j % NSL, j % NSLOT);
+  float4 rin[CTA][4], rinrem[NRA];  // fused form: the layer input rows (LN1's residual)
+  load_rows(X, xv, xrem);
+  if (OP) load_rows(Rin, rin, rinrem);
   wait_vm<0>();
+  retire_rows(xv, xrem);
+  if (OP) retire_rows(rin, rinrem);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LN parameter writes
   __builtin_amdgcn_s_barrier();
 
-  float4 xv[CTA][4], xrem[NRH > 0 ? NRH : 1];  // X rows (B operands of GEMM1 and the residual)
-  f32x16 yacc[CTA];
-  f32x4 yrem[NGA];
-  int tile = blockIdx.x, sl = 0;
-  int wnext = C::AHEAD % NSL;  // packed slot the next ring DMA fetches
   // The slot is consumed as a stream of NFS fragment groups (one ds_read_b128 each = the A operands of 4 MFMAs);
   // group k is requested PD groups before its MFMAs, across chunk and slot boundaries too (the first PD groups and
   // the bias fragments of a chunk are requested under the previous chunk's last MFMAs).
   float4 hb[4], f[NFS + PD];
   {
     const float* slot = ringl;
+    if (!OP) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(slot + NFC * 256 + 4 * (2 * t + half));
+      for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(slot + NFC * 256 + 4 * (2 * t + half));
+    }
 #pragma unroll
     for (int k = 0; k < PD; ++k) f[k] = *reinterpret_cast<const float4*>(slot + k * 256 + lane * 4);
   }
@@ -191,246 +359,219 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   const unsigned long long st_entry = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
   int st_tiles = 0;
 
-  for (int it = 0; it < total; ++it) {
-    const float* slot = ringl + (it % NSLOT) * C::SLOT_FLOATS;
-    const float* nslot = ringl + ((it + 1) % NSLOT) * C::SLOT_FLOATS;
-    if (sl == 0) {  // ---- tile start: B fragments + residual rows straight from global memory (once per 32 NW rows) ----
-      if (stamp) {
-        st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
-        if (st_tiles == 0) st_first_b = st_rt;
-      }
-      // The wave's 32 rows in ACCUMULATOR layout: lane (row m, half) holds columns 32 ct + 8 t + 4 half + (0..3) as one
-      // float4 per (ct, t) -- GEMM1's B operands under the pack's k permutation AND the residual of the tile's end.
-      const int row = min(tile * R + wave * 32 + m, M - 1);  // rows past M repeat row M-1; they are never stored
-      const float* xr = X + (size_t)row * D;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) xv[ct][t] = *reinterpret_cast<const float4*>(xr + 32 * ct + 8 * t + 4 * half);
-#pragma unroll
-      for (int i = 0; i < NRH; ++i) {  // lane half h holds remainder groups g = 2 i + h
-        xrem[i] = float4{0.f, 0.f, 0.f, 0.f};
-        if (2 * i + half < NG) xrem[i] = *reinterpret_cast<const float4*>(xr + 32 * CT + 4 * (2 * i + half));
-      }
-#pragma unroll
-      for (int ct = 0; ct < CTA; ++ct)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) yacc[ct][r] = 0.f;
-#pragma unroll
-      for (int g = 0; g < NGA; ++g) yrem[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // Retire these loads HERE: left to itself hipcc waits for them with counted vmcnt in front of the first MFMAs
-      // of the loop body, in EVERY iteration (it cannot know the loads are not re-issued), and those counts also
-      // drain the ring's LDS-DMA pieces, which share the counter: the ring then runs one slot deep.
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          asm volatile("" : "+v"(xv[ct][t].x), "+v"(xv[ct][t].y), "+v"(xv[ct][t].z), "+v"(xv[ct][t].w));
-#pragma unroll
-      for (int i = 0; i < NRH; ++i)
-        asm volatile("" : "+v"(xrem[i].x), "+v"(xrem[i].y), "+v"(xrem[i].z), "+v"(xrem[i].w));
-    }
-    f32x16 h;
 
-    // The DMA pieces of slot it + AHEAD go out one per fragment group after the slot's barrier (an LDS-DMA issue holds
-    // the wave for 60-180 cycles: one fits in the shadow of a 64-cycle MFMA, a burst of them does not).
-    const bool dma_on = it + C::AHEAD < total;
-    const float* dma_src = ring + (size_t)wnext * C::SLOT_FLOATS + lane * 4;
-    const unsigned dma_dst = ring_base + (unsigned)((it + C::AHEAD) % NSLOT) * (C::SLOT_FLOATS * 4);
-    int dma_g = wave;  // next piece of the slot this wave issues
-    auto issue_piece = [&]() {  // (a piece index past the slot wraps to a piece some other wave also fetches)
-      if (dma_on) {
-        const int g = dma_g < C::SLOT_G ? dma_g : dma_g - C::SLOT_G;
-        dma_piece(dma_src + g * 256, dma_dst + g * 1024);
-        dma_g += NW;
+  // Per ring slot: the lane index is re-derived (two VALU instructions, from inline asm so that it is not hoisted): as
+  // a loop-invariant register it is the first thing hipcc spills at 168 VGPRs, and the reload of a scratch dword sits
+  // behind an s_waitcnt vmcnt(0) that drains the DMA pieces just issued.  The DMA pieces of slot it + AHEAD go out one
+  // per fragment group after the slot's barrier (an LDS-DMA issue holds the wave for 60-180 cycles: one fits in the
+  // shadow of a 64-cycle MFMA, a burst of them does not).
+#define FFD_SLOT_PRELUDE                                                                                               \
+  int lane_i;                                                                                                          \
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_i));                       \
+  const int half_i = lane_i >> 5;                                                                                      \
+  const float* slot = ringl + (it % NSLOT) * C::SLOT_FLOATS;                                                           \
+  const float* nslot = ringl + ((it + 1) % NSLOT) * C::SLOT_FLOATS;                                                    \
+  const bool dma_on = it + C::AHEAD < total;                                                                           \
+  const float* dma_src = slot_src(wnext) + lane_i * 4;                                                                 \
+  const unsigned dma_dst = ring_base + (unsigned)((it + C::AHEAD) % NSLOT) * (C::SLOT_FLOATS * 4);                     \
+  int dma_g = wave; /* next piece of the slot this wave issues */                                                      \
+  auto issue_piece = [&]() { /* (a piece index past the slot wraps to a piece some other wave also fetches) */         \
+    if (dma_on) {                                                                                                      \
+      const int g = dma_g < C::SLOT_G ? dma_g : dma_g - C::SLOT_G;                                                     \
+      dma_piece(dma_src + g * 256, dma_dst + g * 1024);                                                                \
+      dma_g += NW;                                                                                                     \
+    }                                                                                                                  \
+  }
+
+  int it = 0;  // ring slot counter over the whole launch
+  for (int tl = 0; tl < my_tiles; ++tl) {
+    if (stamp) {
+      st_clk = __builtin_amdgcn_s_memtime(), st_rt = __builtin_amdgcn_s_memrealtime();
+      if (st_tiles == 0) st_first_b = st_rt;
+    }
+    if (OP) {
+      // ---- tile start, fused form: x1 = LN1(Rin + Wo attn + bo) of the wave's rows from the out-projection slot ----
+      FFD_SLOT_PRELUDE;
+      if (it > 0) {
+        // the slot's barrier stands at its HEAD here (all waves have just finished a tile together; the rows of this
+        // tile were requested and retired at the end of the previous one): slot it+1 is certified, slot it-1 free
+        wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
       }
-    };
 #pragma unroll
-    for (int K = 0; K < NFS; ++K) {
-      const int c = K / NFC, k = K % NFC;  // chunk of the slot, group of the chunk (compile-time after unrolling)
-      const float4 w = f[K];
-      if (PR) {
-        // Descending priority through the barrier interval: a wave ahead of its SIMD's other waves yields to them
-        // (issue arbitration is priority, then age: at equal priority the oldest wave takes every slot it can use and
-        // the youngest runs the last third of the interval alone, at a lone wave's efficiency).
-        constexpr int KB = (CPS - 1) * NFC + NQ1;  // first group after the slot's barrier
-        const int rel = (K - KB + NFS) % NFS;
-        if (rel == 0 || (rel * 4) / NFS != ((rel - 1) * 4) / NFS) {
-          const int lvl = 3 - (rel * 4) / NFS;  // (the builtin wants a literal; the chain folds after unrolling)
-          if (lvl == 3) __builtin_amdgcn_s_setprio(3);
-          else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
-          else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
+      for (int i = 0; i < C::NPW; ++i) issue_piece();  // (a burst: nothing of this wave's is there to be delayed yet)
+      zero_acc();  // (the accumulators of the out-projection; the FFN's start from zero again below)
+#pragma unroll
+      for (int K = 0; K < NFP; ++K) {
+        const float4 w = f[K];
+        if (PR) {  // descending through the slot, like the chunk slots between their barriers
+          if (K == 0) __builtin_amdgcn_s_setprio(3);
+          else if (K == NFP / 4) __builtin_amdgcn_s_setprio(2);
+          else if (K == NFP / 2) __builtin_amdgcn_s_setprio(1);
+          else if (K == 3 * NFP / 4) __builtin_amdgcn_s_setprio(0);
         }
-      }
-      if (k == 0) {  // the bias is GEMM1's initial accumulator
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h[4 * t] = hb[t].x, h[4 * t + 1] = hb[t].y, h[4 * t + 2] = hb[t].z, h[4 * t + 3] = hb[t].w;
-      }
-      // A group = 4 MFMAs (64 cycles each).  The wave's other work is placed in the gaps BETWEEN them, one kind per
-      // gap (an in-order wave cannot issue past an MFMA the pipe has not accepted yet, so only what sits in a gap
-      // hides under the preceding MFMA): gap 0 relu of the accumulator registers the next GEMM2 group reads, gap 1 the
-      // fragment read PD groups ahead, gap 2 one LDS-DMA piece.
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (k < NQ1) {
-          // ---- GEMM1: H^T chunk (32 hidden x 32 rows), K = D ----
-          const int s = 4 * k + j;
-          if (s < KS2) {
-            const float xb = s < 16 * CT ? f4e(xv[s / 16 < CTA ? s / 16 : 0][(s % 16) / 4], s % 4)
-                                         : f4e(xrem[(s - 16 * CT) / 4 < NRH ? (s - 16 * CT) / 4 : 0], (s - 16 * CT) % 4);
-            h = mfma32(f4e(w, j), xb, h);
+        for (int j = 0; j < 4; ++j) {
+          if (K < NPM) {  // main column tiles, CT independent chains
+            const int idx = 4 * K + j, s = idx / CTA, ct = idx % CTA;
+            if (s < KS2) yacc[ct] = mfma32(f4e(w, j), xb_of(s), yacc[ct]);
+          } else {  // remainder columns on the 4x4x1 form
+            const int idx = 4 * (K - NPM) + j, s = idx / NGA, g = idx % NGA;
+            if (s < KS2) yrem[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4e(w, j), xb_of(s), yrem[g], 0, 0, 0);
           }
-        } else if (k < NQ1 + 4 * CT) {
-          // ---- GEMM2: Y^T += W2[:, chunk] relu(H^T chunk); accumulator register r is the k pair (f_r, f_r + 4) ----
-          const int idx = 4 * (k - NQ1) + j, r = idx / CTA, ct = idx % CTA;
-          yacc[ct] = mfma32(f4e(w, j), h[r], yacc[ct]);
-          if (j == 0) {  // relu (one v_med3_f32 (x, 0, +inf) per element)
+          if (j == 1) {  // request group K + PD (of the next slot, a chunk slot, once past the end)
+            const int KP = K + PD;
+            if (KP < NFP) f[KP] = *reinterpret_cast<const float4*>(slot + KP * 256 + lane_i * 4);
+            else f[KP] = *reinterpret_cast<const float4*>(nslot + (KP - NFP) * 256 + lane_i * 4);
+            if (K == NFP - 1) {
 #pragma unroll
-            for (int rr = 0; rr < RPG; ++rr) {
-              const int rn = (k - NQ1 + 1) * RPG + rr;
-              if (rn < 16) h[rn] = __builtin_amdgcn_fmed3f(h[rn], 0.f, __builtin_inff());
+              for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(nslot + NFC * 256 + 4 * (2 * t + half_i));
             }
           }
-        } else {
-          // remainder columns on the 4x4x1 form
-          const int idx = 4 * (k - NQ1 - 4 * CT) + j, r = idx / NGA, g = idx % NGA;
-          yrem[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4e(w, j), h[r], yrem[g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (j == 1) {
-          // request group K + PD (of the next slot once past the end: certified by this iteration's barrier)
-          const int KP = K + PD;
-          const float* base = KP < NFS ? slot : nslot;
-          const int kk = KP < NFS ? KP : KP - NFS;
-          f[KP] = *reinterpret_cast<const float4*>(base + ((kk / NFC) * SGC + kk % NFC) * 256 + lane * 4);
-          if (k == NFC - 1) {  // bias fragments of the next chunk (of the next slot after the last chunk)
-            const float* bsrc = (c + 1 < CPS) ? slot + ((c + 1) * SGC + NFC) * 256 : nslot + NFC * 256;
+      }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(bsrc + 4 * (2 * t + half));
+      for (int k = 0; k < PD; ++k) f[k] = f[NFP + k];
+      {
+        float4 v[CTA][4], vr[NRA];
+        ln_rows<D>(yacc, yrem, rin, rinrem, lnp + 3 * D, half, v, vr);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) xv[ct][t] = v[ct][t];
+#pragma unroll
+        for (int i = 0; i < NRH; ++i) xrem[i] = (2 * i + half < NG) ? vr[i] : float4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (dma_on && ++wnext == NSL) wnext = 0;
+      ++it;
+    }
+    zero_acc();
+
+    for (int sl = OP ? 1 : 0; sl < NSL; ++sl, ++it) {
+      FFD_SLOT_PRELUDE;
+      f32x16 h;
+#pragma unroll
+      for (int K = 0; K < NFS; ++K) {
+        const int c = K / NFC, k = K % NFC;  // chunk of the slot, group of the chunk (compile-time after unrolling)
+        const float4 w = f[K];
+        if (PR) {
+          // Descending priority through the barrier interval: a wave ahead of its SIMD's other waves yields to them
+          // (issue arbitration is priority, then age: at equal priority the oldest wave takes every slot it can use and
+          // the youngest runs the last third of the interval alone, at a lone wave's efficiency).
+          constexpr int KB = (CPS - 1) * NFC + NQ1;  // first group after the slot's barrier
+          const int rel = (K - KB + NFS) % NFS;
+          if (rel == 0 || (rel * 4) / NFS != ((rel - 1) * 4) / NFS) {
+            const int lvl = 3 - (rel * 4) / NFS;  // (the builtin wants a literal; the chain folds after unrolling)
+            if (lvl == 3) __builtin_amdgcn_s_setprio(3);
+            else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+            else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
           }
         }
-        if (j == 2 && K >= (CPS - 1) * NFC + NQ1 && K < (CPS - 1) * NFC + NQ1 + C::NPW) issue_piece();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (k == NQ1 - 1) {
-        // relu of the accumulator registers the first GEMM2 group reads
+        if (k == 0) {  // the bias is GEMM1's initial accumulator
 #pragma unroll
-        for (int r = 0; r < RPG; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
-        if (c == CPS - 1) {
-          // ---- the slot's barrier: my pieces of slot it+1 have landed; afterwards slot it+1 is readable by
-          //      everyone and nobody reads slot it-1 any more.  In flight and allowed to stay so: the slots after
-          //      it+1 that have been issued (it+2 .. it+AHEAD-1), and the previous tile's stores (younger) ----
-          if (C::AHEAD > 2 && it + C::AHEAD - 1 < total) {
-            if (sl == 0 && it > 0) wait_vm<(C::AHEAD - 2) * C::NPW + C::NST>(); else wait_vm<(C::AHEAD - 2) * C::NPW>();
+          for (int t = 0; t < 4; ++t) h[4 * t] = hb[t].x, h[4 * t + 1] = hb[t].y, h[4 * t + 2] = hb[t].z, h[4 * t + 3] = hb[t].w;
+        }
+        // A group = 4 MFMAs (64 cycles each).  The wave's other work is placed in the gaps BETWEEN them, one kind per
+        // gap (an in-order wave cannot issue past an MFMA the pipe has not accepted yet, so only what sits in a gap
+        // hides under the preceding MFMA): gap 0 relu of the accumulator registers the next GEMM2 group reads, gap 1
+        // the fragment read PD groups ahead, gap 2 one LDS-DMA piece.
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (k < NQ1) {
+            // ---- GEMM1: H^T chunk (32 hidden x 32 rows), K = D ----
+            const int s = 4 * k + j;
+            if (s < KS2) h = mfma32(f4e(w, j), xb_of(s), h);
+          } else if (k < NQ1 + 4 * CT) {
+            // ---- GEMM2: Y^T += W2[:, chunk] relu(H^T chunk); accumulator register r is the k pair (f_r, f_r + 4) ----
+            const int idx = 4 * (k - NQ1) + j, r = idx / CTA, ct = idx % CTA;
+            yacc[ct] = mfma32(f4e(w, j), h[r], yacc[ct]);
+            if (j == 0) {  // relu (one v_med3_f32 (x, 0, +inf) per element)
+#pragma unroll
+              for (int rr = 0; rr < RPG; ++rr) {
+                const int rn = (k - NQ1 + 1) * RPG + rr;
+                if (rn < 16) h[rn] = __builtin_amdgcn_fmed3f(h[rn], 0.f, __builtin_inff());
+              }
+            }
           } else {
-            wait_vm<0>();
+            // remainder columns on the 4x4x1 form
+            const int idx = 4 * (k - NQ1 - 4 * CT) + j, r = idx / NGA, g = idx % NGA;
+            yrem[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4e(w, j), h[r], yrem[g], 0, 0, 0);
           }
-          __builtin_amdgcn_s_barrier();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
+          if (j == 1) {
+            // request group K + PD (of the next slot once past the end: certified by this iteration's barrier)
+            const int KP = K + PD;
+            const float* base = KP < NFS ? slot : nslot;
+            const int kk = KP < NFS ? KP : KP - NFS;
+            f[KP] = *reinterpret_cast<const float4*>(base + ((kk / NFC) * SGC + kk % NFC) * 256 + lane_i * 4);
+            if (k == NFC - 1) {  // bias fragments of the next chunk (of the next slot after the last chunk)
+              const float* bsrc = (c + 1 < CPS) ? slot + ((c + 1) * SGC + NFC) * 256 : nslot + NFC * 256;
 #pragma unroll
-    for (int k = 0; k < PD; ++k) f[k] = f[NFS + k];
-    if (dma_on && ++wnext == NSL) wnext = 0;
-
-    if (++sl == NSL) {  // ---- tile end: + b2, + residual, LayerNorm2, float4 stores ----
-      sl = 0;
-      if (stamp) {
-        const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
-        st_acc += __builtin_amdgcn_s_memtime() - st_clk;
-        st_acc_rt += rt - st_rt;
-        if (st_tiles == 0) st_first_e = rt;
-      }
-      // yacc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]: four consecutive columns per (ct, t)
-      float4 v[CTA][4], vr[NRH > 0 ? NRH : 1];
-      float sum = 0.f;
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float4 bq = *reinterpret_cast<const float4*>(&lnp[32 * ct + 8 * t + 4 * half]);
-          const float4 x4 = xv[ct][t];
-          v[ct][t] = float4{x4.x + (yacc[ct][4 * t] + bq.x), x4.y + (yacc[ct][4 * t + 1] + bq.y),
-                            x4.z + (yacc[ct][4 * t + 2] + bq.z), x4.w + (yacc[ct][4 * t + 3] + bq.w)};
-          sum += (v[ct][t].x + v[ct][t].y) + (v[ct][t].z + v[ct][t].w);
-        }
-      if (NG > 0) {
-        // the two lane halves hold partial sums over their own hidden units: add them (both halves get the total);
-        // half h then finishes groups g = 2 i + h
-#pragma unroll
-        for (int i = 0; i < (NG + 1) / 2; ++i) {
-          float a[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float t0 = yrem[2 * i][e];
-            t0 += __shfl_xor(t0, 32);
-            float t1 = 0.f;
-            if (2 * i + 1 < NG) {
-              t1 = yrem[(2 * i + 1 < NG) ? 2 * i + 1 : 0][e];
-              t1 += __shfl_xor(t1, 32);
+              for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(bsrc + 4 * (2 * t + half_i));
             }
-            a[e] = half ? t1 : t0;
           }
-          vr[i] = float4{0.f, 0.f, 0.f, 0.f};
-          if (2 * i + half < NG) {
-            const float4 bq = *reinterpret_cast<const float4*>(&lnp[32 * CT + 4 * (2 * i + half)]);
-            const float4 x4 = xrem[i];
-            vr[i] = float4{x4.x + (a[0] + bq.x), x4.y + (a[1] + bq.y), x4.z + (a[2] + bq.z), x4.w + (a[3] + bq.w)};
-            sum += (vr[i].x + vr[i].y) + (vr[i].z + vr[i].w);
+          if (j == 2 && K >= (CPS - 1) * NFC + NQ1 && K < (CPS - 1) * NFC + NQ1 + C::NPW) issue_piece();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (k == NQ1 - 1) {
+          // relu of the accumulator registers the first GEMM2 group reads
+#pragma unroll
+          for (int r = 0; r < RPG; ++r) h[r] = __builtin_amdgcn_fmed3f(h[r], 0.f, __builtin_inff());
+          if (c == CPS - 1) {
+            // ---- the slot's barrier: my pieces of slot it+1 have landed; afterwards slot it+1 is readable by
+            //      everyone and nobody reads slot it-1 any more.  In flight and allowed to stay so: the slots after
+            //      it+1 that have been issued (it+2 .. it+AHEAD-1), and the previous tile's stores (younger) ----
+            if (C::AHEAD > 2 && it + C::AHEAD - 1 < total) {
+              if (sl == 0 && it > 0) wait_vm<(C::AHEAD - 2) * C::NPW + C::NST>(); else wait_vm<(C::AHEAD - 2) * C::NPW>();
+            } else {
+              wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum * (1.0f / D);
-      float ss = 0.f;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float a = v[ct][t].x - mean, b = v[ct][t].y - mean, c2 = v[ct][t].z - mean, d = v[ct][t].w - mean;
-          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
-        }
-#pragma unroll
-      for (int i = 0; i < (NG + 1) / 2; ++i)
-        if (2 * i + half < NG) {
-          const float a = vr[i].x - mean, b = vr[i].y - mean, c2 = vr[i].z - mean, d = vr[i].w - mean;
-          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c2, c2, ss), ss = fmaf(d, d, ss);
-        }
-      ss += __shfl_xor(ss, 32);
-      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+      for (int k = 0; k < PD; ++k) f[k] = f[NFS + k];
+      if (dma_on && ++wnext == NSL) wnext = 0;
+    }
+
+    // ---- tile end: + b2, + residual, LayerNorm2, float4 stores ----
+    if (stamp) {
+      const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+      st_acc += __builtin_amdgcn_s_memtime() - st_clk;
+      st_acc_rt += rt - st_rt;
+      if (st_tiles == 0) st_first_e = rt;
+    }
+    {
+      float4 v[CTA][4], vr[NRA];
+      ln_rows<D>(yacc, yrem, xv, xrem, lnp, half, v, vr);
       const int row = tile * R + wave * 32 + m;
       if (row < M) {
         float* yr = Y + (size_t)row * D;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int c0 = 32 * ct + 8 * t + 4 * half;
-            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + c0]);
-            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + c0]);
-            *reinterpret_cast<float4*>(yr + c0) =
-                float4{(v[ct][t].x - mean) * rstd * g4.x + e4.x, (v[ct][t].y - mean) * rstd * g4.y + e4.y,
-                       (v[ct][t].z - mean) * rstd * g4.z + e4.z, (v[ct][t].w - mean) * rstd * g4.w + e4.w};
-          }
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<float4*>(yr + 32 * ct + 8 * t + 4 * half) = v[ct][t];
 #pragma unroll
         for (int i = 0; i < (NG + 1) / 2; ++i)
-          if (2 * i + half < NG) {
-            const int c0 = 32 * CT + 4 * (2 * i + half);
-            const float4 g4 = *reinterpret_cast<const float4*>(&lnp[D + c0]);
-            const float4 e4 = *reinterpret_cast<const float4*>(&lnp[2 * D + c0]);
-            *reinterpret_cast<float4*>(yr + c0) =
-                float4{(vr[i].x - mean) * rstd * g4.x + e4.x, (vr[i].y - mean) * rstd * g4.y + e4.y,
-                       (vr[i].z - mean) * rstd * g4.z + e4.z, (vr[i].w - mean) * rstd * g4.w + e4.w};
-          }
+          if (2 * i + half < NG) *reinterpret_cast<float4*>(yr + 32 * CT + 4 * (2 * i + half)) = vr[i];
       }
-      if (stamp) {
-        if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
-        ++st_tiles;
-      }
-      tile += gridDim.x;
+    }
+    if (stamp) {
+      if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
+      ++st_tiles;
+    }
+    tile += gridDim.x;
+    if (tl + 1 < my_tiles) {  // the next tile's rows (the first tile's came with the ring fill)
+      load_rows(X, xv, xrem);
+      if (OP) load_rows(Rin, rin, rinrem);
+      retire_rows(xv, xrem);
+      if (OP) retire_rows(rin, rinrem);
     }
   }
+#undef FFD_SLOT_PRELUDE
   if (stamp && threadIdx.x == 0) {
     unsigned long long* o = stamp + 8 * (size_t)blockIdx.x;
     o[0] = st_acc, o[1] = st_acc_rt, o[2] = st_entry, o[3] = st_first_b, o[4] = st_first_e, o[5] = st_epi;
@@ -442,36 +583,56 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
 int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
 int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
 int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
+int g_ffn_rows_prio = 1;  // descending wave priority through a barrier interval (ffd_tune "ffn_rows_prio")
+int g_ffn_rows_fuse = 1;  // out-projection + LN1 inside the kernel (ffd_tune "ffn_rows_fuse"; two-chunk slots only)
 
 bool ffn_rows_supported(int D, int F) { return D == 72 && F % 64 == 0 && F >= 64; }
 // large M: where k_ffn_ln ran its 64-row persistent form
 bool ffn_rows_selected(int M, int D, int F) {
   return g_ffn_rows && ffn_rows_supported(D, F) && (g_ffn_rows == 2 || cdiv(M, 64) >= 512);
 }
+// the fused form (out-proj + LN1 + FFN + LN2 in one launch) is taken where k_ffn_rows is, with two-chunk ring slots
+bool ffn_rows_fused_selected(int M, int D, int F) {
+  return g_ffn_rows_fuse && g_ffn_rows_cps != 1 && g_ffn_rows_nw != 6 && ffn_rows_selected(M, D, F);
+}
 
-int g_ffn_rows_prio = 1;  // descending wave priority through a barrier interval (ffd_tune "ffn_rows_prio")
+struct RowsArgs {
+  const float *X, *Rin;  // fused: attention output + layer input; else the FFN input (Rin unused)
+  const LayerWeights* w;
+  float* Y;
+  int M, F;
+  bool fused;
+  unsigned long long* stamp;
+};
 
 template <int D, int NW, int CPS, int NSLOT>
-static hipError_t launch_rows_cfg(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
-                                  unsigned long long* stamp) {
+static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
   const int R = 32 * NW;
-  const int ntiles = cdiv(M, R);
+  const int ntiles = cdiv(a.M, R);
   // workgroups per CU: as many rings as fit the 160 KB of LDS and 12 waves
   constexpr int per_cu_lds = (160 * 1024) / (FfnRowsCfg<D, NW, CPS, NSLOT>::LDS_FLOATS * 4);
   constexpr int per_cu = per_cu_lds < 12 / NW ? per_cu_lds : 12 / NW;
   const int slots = per_cu * num_cus();
   const int grid = ntiles < slots ? ntiles : slots;
-  if (g_ffn_rows_prio && NW > 4)
-    hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, 1>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
-  else
-    hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, 0>), dim3(grid), dim3(64 * NW), 0, s, X, w.ring, w.b2, w.n2w, w.n2b, Y, M, F, stamp);
+  const LayerWeights& w = *a.w;
+#define FFD_ROWS_LAUNCH(PR, OP)                                                                                        \
+  hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, PR, OP>), dim3(grid), dim3(64 * NW), 0, s, a.X, a.Rin, w.ring,      \
+                     w.ring_op, w.b2, w.n2w, w.n2b, w.out_b, w.n1w, w.n1b, a.Y, a.M, a.F, a.stamp)
+  if constexpr (CPS == 2 && NSLOT == 3 && NW != 6) {
+    if (a.fused) {
+      if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, true); else FFD_ROWS_LAUNCH(0, true);
+      return hipGetLastError();
+    }
+  }
+  if (a.fused) return hipErrorInvalidValue;
+  if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, false); else FFD_ROWS_LAUNCH(0, false);
+#undef FFD_ROWS_LAUNCH
   return hipGetLastError();
 }
 
-hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
-                           unsigned long long* stamp) {
-  if (M <= 0) return hipSuccess;
-  if (!ffn_rows_supported(D, F) || w.ring == nullptr) return hipErrorInvalidValue;
+static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s) {
+  if (a.M <= 0) return hipSuccess;
+  if (!ffn_rows_supported(D, a.F) || a.w->ring == nullptr || (a.fused && a.w->ring_op == nullptr)) return hipErrorInvalidValue;
   // Waves per workgroup: a tile is 32 NW rows and every CU walks ceil(tiles / CUs) of them at NW / 4 waves per SIMD.
   // Pick the NW with the least estimated time = passes x waves per SIMD / measured main-loop efficiency
   // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
@@ -482,21 +643,33 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
     double best = 0.0;
     for (int i = 2; i >= 0; --i) {
       const int cand = 4 * (i + 1);
-      const double t = (double)cdiv(cdiv(M, 32 * cand), num_cus()) * (i + 1) / eff[i];
+      const double t = (double)cdiv(cdiv(a.M, 32 * cand), num_cus()) * (i + 1) / eff[i];
       if (best == 0.0 || t < best * 0.999) best = t, nw = cand;
     }
   }
   const int cps = g_ffn_rows_cps == 1 ? 1 : 2;  // 32-unit chunks per ring slot = per barrier (ffd_tune "ffn_rows_cps")
   switch (nw * 10 + cps) {
     case 61:
-    case 62: return launch_rows_cfg<72, 6, 1, 3>(X, w, Y, M, F, s, stamp);  // two workgroups (two rings) per CU
-    case 41: return launch_rows_cfg<72, 4, 1, 4>(X, w, Y, M, F, s, stamp);
-    case 42: return launch_rows_cfg<72, 4, 2, 3>(X, w, Y, M, F, s, stamp);
-    case 81: return launch_rows_cfg<72, 8, 1, 4>(X, w, Y, M, F, s, stamp);
-    case 82: return launch_rows_cfg<72, 8, 2, 3>(X, w, Y, M, F, s, stamp);
-    case 121: return launch_rows_cfg<72, 12, 1, 4>(X, w, Y, M, F, s, stamp);
-    default: return launch_rows_cfg<72, 12, 2, 3>(X, w, Y, M, F, s, stamp);
+    case 62: return launch_rows_cfg<72, 6, 1, 3>(a, s);  // two workgroups (two rings) per CU
+    case 41: return launch_rows_cfg<72, 4, 1, 4>(a, s);
+    case 42: return launch_rows_cfg<72, 4, 2, 3>(a, s);
+    case 81: return launch_rows_cfg<72, 8, 1, 4>(a, s);
+    case 82: return launch_rows_cfg<72, 8, 2, 3>(a, s);
+    case 121: return launch_rows_cfg<72, 12, 1, 4>(a, s);
+    default: return launch_rows_cfg<72, 12, 2, 3>(a, s);
   }
+}
+
+hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
+                           unsigned long long* stamp) {
+  return launch_rows_any(RowsArgs{X, nullptr, &w, Y, M, F, false, stamp}, D, s);
+}
+
+// Y = LN2(x1 + FFN(x1)), x1 = LN1(Rin + Wo attn + bo): cached_transformer.py:316-327 in one launch.  Y must not alias
+// attn or Rin (a wave's stores and another wave's loads are not ordered).
+hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const LayerWeights& w, float* Y, int M, int D,
+                                 int F, hipStream_t s, unsigned long long* stamp) {
+  return launch_rows_any(RowsArgs{attn, Rin, &w, Y, M, F, true, stamp}, D, s);
 }
 
 }  // namespace ffd

@@ -23,6 +23,25 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 
 constexpr __host__ __device__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- LDS-DMA issued by hand + counted waits (k_ffn_rows, k_linear_res_ln) ----
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS bytes [lds_byte, lds_byte + 1024).
+// Issued from inline asm on purpose: for the builtin form hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
+// next ds_read of the same __shared__ array (it cannot tell the ring's slots apart), which drains the ring every slot.
+// The kernels order DMA and reads themselves: counted vmcnt (+ s_barrier where waves share the image).
+__device__ __forceinline__ void dma_piece(const float* g, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_byte), "v"(g)
+               : "memory");  // (m0 is a reserved register: hipcc keeps nothing in it across statements)
+}
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+  return (unsigned)(unsigned long)((const __attribute__((address_space(3))) float*)p);
+}
+
+
 // Padded LDS row stride (in floats) for a (rows x D) fp32 tile whose MFMA
 // fragments are read with ds_read_b32 as tile[(l&15)*stride + 4s + (l>>4)]:
 // stride/2 odd => the 16 rows x 2 k of each 32-lane half hit 32 distinct banks.
@@ -54,6 +73,7 @@ struct LayerWeights {
   const float *w2p;     // w2pack
   const float *w2r;     // w2rem (remainder rows d % 16 of linear2.weight, 4x4x1 MFMA A-operand order)
   const float* ring = nullptr;  // CU-shared weight ring pack of the row-owning FFN (ffd_ffn_rows.hip)
+  const float* ring_op = nullptr;  // its out-projection slot (fused out-proj + LN1 form)
   const void *w1s = nullptr, *w2s = nullptr;  // three-part bf16 packs of the opt-in split FFN (ffd_ffn_split.hip)
 };
 
@@ -116,7 +136,13 @@ size_t ffn_ring_floats(int D, int F);
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
 hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                            unsigned long long* stamp = nullptr);
-extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_prio;
+extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_prio, g_ffn_rows_fuse;
+// out-proj + LN1 + FFN + LN2 in one launch (the fused form of k_ffn_rows); Y must not alias attn / Rin
+bool ffn_rows_fused_selected(int M, int D, int F);
+size_t ffn_ring_oproj_floats(int D);
+hipError_t launch_pack_oproj_ring(const float* Wo, float* out, int D, hipStream_t s);
+hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const LayerWeights& w, float* Y, int M, int D,
+                                 int F, hipStream_t s, unsigned long long* stamp = nullptr);
 // Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
 // workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
 int small_path_splits(int M, int D, int F);

@@ -222,33 +222,55 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
     gq[ct] = in ? *reinterpret_cast<const float4*>(gam + n) : float4{0.f, 0.f, 0.f, 0.f};
     eq[ct] = in ? *reinterpret_cast<const float4*>(bet + n) : float4{0.f, 0.f, 0.f, 0.f};
   }
+  // The DMA goes out from inline asm (dma_piece) and the kernel orders it against its LDS reads itself: for the
+  // builtin form hipcc put s_waitcnt vmcnt(0) in front of every ds_read of `imgs` -- also the residual reads of the
+  // CURRENT tile, right after the NEXT tile's DMA had been issued -- so nothing but the MFMAs overlapped the DMA
+  // latency, and the top of the loop waited for the previous tile's stores to retire as well.
+  const unsigned img_base = __builtin_amdgcn_readfirstlane(lds_addr(&imgs[0][0][0][0]));
+  constexpr unsigned IMG_BYTES = TR * SX * 4;
   auto issue_dma = [&](int t, int b) {  // rows past M repeat the last valid row (never stored)
     const int rows_valid = min(TR, M - t * TR);
     const size_t base = (size_t)t * TR * D;
+    const unsigned dx = img_base + (unsigned)((wave * 2 + b) * 2) * IMG_BYTES;
 #pragma unroll
     for (int pc = 0; pc < NPC; ++pc) {
       const int p = pc * 64 + lane;
       const int r = p / S4, c4 = p - r * S4;
       const size_t off = base + (size_t)min(r, rows_valid - 1) * D + 4 * min(c4, D / 4 - 1);
       if (p < TR * S4) {
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(X + off), (lds_ptr_t)(&imgs[wave][b][0][pc * 256]), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(R + off), (lds_ptr_t)(&imgs[wave][b][1][pc * 256]), 16, 0, 0);
+        dma_piece(X + off, dx + pc * 1024);
+        dma_piece(R + off, dx + IMG_BYTES + pc * 1024);
       }
     }
   };
+  // The parameter loads retire HERE: left to itself hipcc waits for them in front of their first use inside the
+  // loop, in every iteration, with a count that also drains the DMA pieces issued just before (they share vmcnt).
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      asm volatile("" : "+v"(wq[ct][g].x), "+v"(wq[ct][g].y), "+v"(wq[ct][g].z), "+v"(wq[ct][g].w));
+    asm volatile("" : "+v"(bq[ct].x), "+v"(bq[ct].y), "+v"(bq[ct].z), "+v"(bq[ct].w));
+    asm volatile("" : "+v"(gq[ct].x), "+v"(gq[ct].y), "+v"(gq[ct].z), "+v"(gq[ct].w));
+    asm volatile("" : "+v"(eq[ct].x), "+v"(eq[ct].y), "+v"(eq[ct].z), "+v"(eq[ct].w));
+  }
 
+  constexpr int NSTI = cdiv(TR * (D / 4), 64);  // store instructions of a full tile
   int buf = 0;
   const int tstep = (int)gridDim.x * 4;
   int tile = blockIdx.x * 4 + wave;
-  if (tile < ntiles) issue_dma(tile, 0);
+  if (tile >= ntiles) return;  // (no workgroup barrier anywhere in this kernel)
+  issue_dma(tile, 0);
+  wait_vm<0>();
   for (; tile < ntiles; tile += tstep, buf ^= 1) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this tile's images have landed (and the previous tile's stores left)
+    // this tile's images have landed: certified before the loop / at the end of the previous iteration
     float* xs = imgs[wave][buf][0];
     const float* rs = imgs[wave][buf][1];
     float xf[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) xf[s] = xs[(lane & 15) * SX + 4 * s + (lane >> 4)];
-    if (tile + tstep < ntiles) issue_dma(tile + tstep, buf ^ 1);
+    const bool more = tile + tstep < ntiles;
+    if (more) issue_dma(tile + tstep, buf ^ 1);
 
     f32x4 acc[CT];
 #pragma unroll
@@ -314,10 +336,21 @@ __global__ __launch_bounds__(256, 2) void k_linear_res_ln(const float* __restric
     const int row0 = tile * TR;
     float4* y4 = reinterpret_cast<float4*>(Y + (size_t)row0 * D);
     const int nvalid = min(16, M - row0);
-    for (int f = lane; f < 16 * (D / 4); f += 64) {
+    float4 o4[NSTI];
+#pragma unroll
+    for (int i = 0; i < NSTI; ++i) {
+      const int f = min(lane + 64 * i, 16 * (D / 4) - 1);
       const int r = f / (D / 4), c4 = f - r * (D / 4);
-      if (r < nvalid) y4[f] = *reinterpret_cast<const float4*>(xs + r * SX + 4 * c4);
+      o4[i] = *reinterpret_cast<const float4*>(xs + r * SX + 4 * c4);
     }
+#pragma unroll
+    for (int i = 0; i < NSTI; ++i) {
+      const int f = lane + 64 * i;
+      if (f < 16 * (D / 4) && f / (D / 4) < nvalid) y4[f] = o4[i];
+    }
+    // The next tile's images (issued before this tile's MFMAs) have landed; this tile's NSTI stores, younger, stay in
+    // flight.  (A tile with a successor is a full tile: every one of its store instructions has active lanes.)
+    if (more) wait_vm<NSTI>();
   }
 }
 

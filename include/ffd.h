@@ -292,8 +292,12 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
  *                                              every M where the small- / mid-batch forms are off (test suite);
- *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave);
+ *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave); 6 = two
+ *                                              6-wave workgroups per CU (does not co-reside on this chip: tests only);
  *   "ffn_rows_cps" = 0 | 2 | 1                 32-unit chunks per ring slot (= per barrier) of k_ffn_rows (default 2);
+ *   "ffn_rows_fuse" = 1 | 0                    out-projection + residual + LN1 inside k_ffn_rows (one more ring slot per
+ *                                              tile; two-chunk slots only) or k_linear_res_ln in front of it;
+ *   "ffn_rows_prio" = 1 | 0                    descending wave priority through a barrier interval of k_ffn_rows;
  *   "ffn_persist" = 1 | 0 | n                  k_ffn_ln at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
  *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
  *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most

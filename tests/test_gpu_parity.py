@@ -256,12 +256,13 @@ def _tune_defaults():
         assert N.lib().ffd_tune(b"reset", 0) == 0
 
 
-@pytest.fixture(params=["auto", "large", "rows", "unfused", "split"])
+@pytest.fixture(params=["auto", "large", "rows", "rows_unfused", "unfused", "split"])
 def variant(request, ffd):
     """Kernel variants that must all meet the same parity bar: default heuristics (at these small batches: the
     q-/key-split fused attention kernel and the F-split out-proj + FFN pair), "large" (the kernels the heuristics pick
     at large batches, forced: one workgroup per head (pair), k_linear_res_ln + k_ffn_ln), "rows" (the same with the
-    large-batch FFN of d_model 72 forced at every size: k_ffn_rows, row-owning waves under the LDS weight ring) and the two-kernel
+    large-batch FFN of d_model 72 forced at every size: k_ffn_rows, row-owning waves under the LDS weight ring, with the
+    out-projection + LN1 inside it; "rows_unfused": with k_linear_res_ln in front of it instead) and the two-kernel
     projection / attention fallback ("unfused"); and "split": the opt-in FFN on the bf16 matrix cores as a three-part,
     six-term split (fp32-equivalent, csrc/ffd_ffn_split.hip), which has to pass the same goldens at the same tolerance."""
     from fastfourierdiffusion_amd import _native as N
@@ -271,11 +272,13 @@ def variant(request, ffd):
         assert lib.ffd_tune(b"ffn_split", 1) == 0
     if request.param == "unfused":
         assert lib.ffd_tune(b"attn_fused", 0) == 0
-    if request.param in ("large", "rows"):
+    if request.param in ("large", "rows", "rows_unfused"):
         assert lib.ffd_tune(b"attn_small", 0) == 0
         assert lib.ffd_tune(b"small_path", 0) == 0
-    if request.param == "rows":
+    if request.param in ("rows", "rows_unfused"):
         assert lib.ffd_tune(b"mid_path", 0) == 0 and lib.ffd_tune(b"ffn_rows", 2) == 0
+    if request.param == "rows_unfused":
+        assert lib.ffd_tune(b"ffn_rows_fuse", 0) == 0
     yield request.param
     lib.ffd_tune(b"reset", 0)
 
@@ -1274,24 +1277,33 @@ def test_config5_shard_cached_modes_at_size(ffd, B):
 
 def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     """The FFN at large M is k_ffn_rows: row-owning waves (32 rows each, whole hidden dimension) under a CU-shared LDS
-    weight ring.  Which wave of which workgroup owns a row, and how many chunks a ring slot holds, must not show in the
-    result: the ECG B = 512 score is bit-identical for 4 / 6 / 8 / 12 waves per workgroup (tiles of 128 / 192 / 256 / 384
-    rows; 6 waves = two workgroups with a ring each per CU) and for one or two chunks per slot; a ragged last tile (M = 513 * 187 rows) stays finite
-    and independent; the F-split kernel it replaces (k_ffn_ln, other summation order) agrees to rounding."""
+    weight ring; by default the out-projection + LN1 run inside it too, from one more ring slot (two-chunk slots).
+    Which wave of which workgroup owns a row, and how many chunks a ring slot holds, must not show in the result: the
+    ECG B = 512 score is bit-identical for 4 / 6 / 8 / 12 waves per workgroup (tiles of 128 / 192 / 256 / 384 rows;
+    6 waves = two workgroups with a ring each per CU) and for one or two chunks per slot in the unfused form, and for
+    4 / 8 / 12 waves in the fused form; fused and unfused agree to rounding (other k order in the out-projection); a
+    ragged last tile (M = 513 * 187 rows) stays finite and independent; the F-split kernel it replaces (k_ffn_ln,
+    other summation order) agrees to rounding."""
     from fastfourierdiffusion_amd import _native as N
 
     c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
     m, _ = make_model(ffd, c)
     lib = N.lib()
     x = torch.from_numpy(next(synthetic.noise_stream((513, c["L"], c["C"]), 1, 909))).cuda()
-    outs = {}
-    for nw, cps in ((0, 0), (4, 1), (4, 2), (6, 1), (8, 1), (8, 2), (12, 1), (12, 2)):
-        assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", cps) == 0
-        outs[(nw, cps)] = m(batch_of(x[:512].contiguous(), 0.3))
-    ref = outs[(0, 0)]
-    for k, v in outs.items():
-        assert torch.equal(ref, v), k
+    refs = {}
+    for fuse, cfgs in ((0, ((0, 0), (4, 1), (4, 2), (6, 1), (8, 1), (8, 2), (12, 1), (12, 2))),
+                       (1, ((0, 0), (4, 2), (8, 2), (12, 2)))):
+        outs = {}
+        for nw, cps in cfgs:
+            assert lib.ffd_tune(b"ffn_rows_fuse", fuse) == 0
+            assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", cps) == 0
+            outs[(nw, cps)] = m(batch_of(x[:512].contiguous(), 0.3))
+        refs[fuse] = outs[(0, 0)]
+        for k, v in outs.items():
+            assert torch.equal(refs[fuse], v), (fuse, k)
+    assert rel_err(refs[0].cpu(), refs[1].cpu()) < 2e-6
     assert lib.ffd_tune(b"reset", 0) == 0
+    ref = refs[1]  # the default form
     ragged = m(batch_of(x, 0.3))
     assert torch.isfinite(ragged).all()
     assert torch.equal(ragged[:512], ref)  # a row's result does not depend on the batch around it

@@ -7,8 +7,8 @@ from a loaded value) that the compiler turned into a no-op -- the root of the ca
 loop-carried bias fragment dropped; only builds with that bug carry the comment).
 
 usage: tools/check_mfma_operands.py file.s [kernel-substring]     (file.s from hipcc -S --cuda-device-only)
-Linear scan per kernel (program order, ignoring control flow): exact for straight-line loop bodies, conservative
-elsewhere -- read a report as "look at this", not as proof."""
+Linear scan per basic block (the state is dropped at every branch target): exact for straight-line loop bodies --
+read a report as "look at this", not as proof."""
 import re, sys
 
 def regs(tok):
@@ -29,6 +29,9 @@ def scan(name, lines):
     bad = []
     for ln, t in lines:
         t = t.split(";")[0].strip()
+        if t.startswith(".LBB"):  # a branch target: what the registers hold depends on the edge taken (a rotated loop
+            group, dirty, pending = {}, {}, []  # puts the tail of its body in front of the head); track per block
+            continue
         if not t or t.startswith("."):
             continue
         parts = re.split(r"\s+", t, maxsplit=1)
@@ -51,6 +54,19 @@ def scan(name, lines):
                             if group[pr] == group[r] and pr != r and ppos == pos and d[0] > group[r][0] and \
                                     use not in [b[1] for b in bad]:
                                 bad.append((pr, use, d, (ln, t)))
+            for r in regs(ops[0]):  # the destination holds accumulator values from here on, not a loaded fragment
+                group.pop(r, None)  # (an accumulator initialised by a load, e.g. a bias fragment, and relu'd later)
+                dirty.pop(r, None)
+            pending = [p for p in pending if p[0] not in regs(ops[0])]
+            continue
+        if op.startswith("v_mov_b32") and len(ops) == 2 and regs(ops[1]) and all(
+                q in group and q not in dirty for q in regs(ops[1])):
+            # a plain copy of an unmodified loaded value (hipcc re-homing a row register at a tile start): the
+            # destination carries loaded data again, under no fragment of its own
+            for r in regs(ops[0]):
+                group.pop(r, None)
+                dirty.pop(r, None)
+            pending = [p for p in pending if p[0] not in regs(ops[0])]
             continue
         if op.startswith("v_") and ops:
             for r in regs(ops[0]):

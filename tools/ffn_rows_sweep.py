@@ -1,5 +1,5 @@
 """Row-owning FFN configurations (waves per workgroup x row blocks per wave): launch time and in-kernel main-loop
-efficiency (MFMA issue cycles of a tile / stamped cycles of its main loop).\ntools/ffn_rows_sweep.py [B] [cfgs nw:cps[:prio],..]"""
+efficiency (MFMA issue cycles of a tile / stamped cycles of its main loop).\ntools/ffn_rows_sweep.py [B] [cfgs nw:cps[:prio[:fuse]],..]"""
 import ctypes as C, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -17,6 +17,8 @@ out = []
 for cfg in cfgs:
   nw, mb = cfg[:2]
   prio = cfg[2] if len(cfg) > 2 else 1
+  fuse = cfg[3] if len(cfg) > 3 else 1
+  assert lib.ffd_tune(b"ffn_rows_fuse", fuse) == 0
   for dbg in dbgs:
     assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", mb) == 0
     assert lib.ffd_tune(b"ffn_rows_prio", prio) == 0
@@ -32,7 +34,7 @@ for cfg in cfgs:
     loop_us = float(np.median((r[:, 4] - r[:, 3]) * 0.01))
     wps = {4: 1, 8: 2, 12: 3, 6: 3}[nw]  # waves per SIMD (nw = 6: two workgroups per CU)
     mf = (68 * 64 + (0 if dbg & 1 else 32 * 8)) * 64 * wps  # MFMA issue cycles per SIMD and tile (32 rows per wave)
-    out.append({"nw": nw, "mb": mb, "prio": prio, "kernel_us": round(best, 1), "ghz": round(ghz.value, 3),
+    out.append({"nw": nw, "mb": mb, "prio": prio, "fuse": fuse, "kernel_us": round(best, 1), "ghz": round(ghz.value, 3),
                 "tile_loop_us": round(loop_us, 1), "loop_eff": round(mf / (loop_us * ghz.value * 1e3), 3),
                 "exit_us_max": round(float(((r[:, 6] - r[:, 2].min()) * 0.01).max()), 1),
                 # per-workgroup phases (median us): entry ramp over the grid, prologue (LN parameters + first ring
