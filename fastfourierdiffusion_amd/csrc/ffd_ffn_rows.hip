@@ -232,18 +232,65 @@ __device__ __forceinline__ void ln_rows(const f32x16* acc, const f32x4* rem, con
     }
 }
 
+// The sliced form's tile end: the wave's partial rows as they are (slice 0: + bias + residual), same layout as ln_rows.
+template <int D>
+__device__ __forceinline__ void raw_rows(const f32x16* acc, const f32x4* rem, const float4 (*res)[4], const float4* resrem,
+                                         const float* p, int half, bool first, float4 (*v)[4], float4* vr) {
+  constexpr int CT = ring_ct(D), NG = ring_ng(D);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[ct][t] = float4{acc[ct][4 * t], acc[ct][4 * t + 1], acc[ct][4 * t + 2], acc[ct][4 * t + 3]};
+      if (first) {
+        const float4 bq = *reinterpret_cast<const float4*>(&p[32 * ct + 8 * t + 4 * half]);
+        const float4 x4 = res[ct][t];
+        v[ct][t] = float4{x4.x + (v[ct][t].x + bq.x), x4.y + (v[ct][t].y + bq.y), x4.z + (v[ct][t].z + bq.z),
+                          x4.w + (v[ct][t].w + bq.w)};
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < (NG + 1) / 2; ++i) {
+    float a[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t0 = rem[2 * i][e];
+      t0 += __shfl_xor(t0, 32);
+      float t1 = 0.f;
+      if (2 * i + 1 < NG) {
+        t1 = rem[(2 * i + 1 < NG) ? 2 * i + 1 : 0][e];
+        t1 += __shfl_xor(t1, 32);
+      }
+      a[e] = half ? t1 : t0;
+    }
+    vr[i] = float4{a[0], a[1], a[2], a[3]};
+    if (first && 2 * i + half < NG) {
+      const float4 bq = *reinterpret_cast<const float4*>(&p[32 * CT + 4 * (2 * i + half)]);
+      const float4 x4 = resrem[i];
+      vr[i] = float4{x4.x + (a[0] + bq.x), x4.y + (a[1] + bq.y), x4.z + (a[2] + bq.z), x4.w + (a[3] + bq.w)};
+    }
+  }
+}
+
 // OP (fused form, cached_transformer.py:316-327 in one launch): X is the ATTENTION output and Rin the layer input; a
 // tile starts with one extra ring slot -- the out-projection fragments (`ringp`) -- from which every wave computes
 // x1 = LayerNorm1(Rin + Wo attn + bo) of its 32 rows on the same two MFMA forms; x1 never leaves the registers (it is
 // GEMM1's B operand and LN2's residual).  Without OP, X is x1 itself (k_linear_res_ln wrote it).
-template <int D, int NW, int CPS, int NSLOT, int PR, bool OP>
+// SL (sliced form, mid-size M; with OP only): workgroup u takes tile u / nslice and the hidden units of slice u % nslice
+// only (its share of the chunk slots, after the out-projection slot every slice recomputes), and stores its partial rows
+// raw -- slice 0 with x1 + b2 added -- to Y[slice][M][D]; k_rows_reduce_ln adds the slices in order and normalises.
+// One unit per workgroup (the grid is tiles x nslice <= the CUs).
+// ONE: at most one tile per workgroup (the grid covers the tiles: ECG B = 512 is 250 tiles of 384 rows): the tile loop
+// is gone at compile time, and with it the loop-carried row registers that cost the fused form 68 B of scratch.
+template <int D, int NW, int CPS, int NSLOT, int PR, bool OP, bool SL, bool ONE>
 __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict__ X, const float* __restrict__ Rin,
                                                              const float* __restrict__ ring, const float* __restrict__ ringp,
                                                              const float* __restrict__ b2, const float* __restrict__ gam,
                                                              const float* __restrict__ bet, const float* __restrict__ bo,
                                                              const float* __restrict__ gam1, const float* __restrict__ bet1,
-                                                             float* __restrict__ Y, int M, int F,
+                                                             float* __restrict__ Y, int M, int F, int nslice,
                                                              unsigned long long* stamp) {
+  static_assert(!SL || OP, "the sliced form recomputes the out-projection per slice");
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): the record k_ffn_ln writes (8 x u64 per
   // workgroup), to memory nothing else reads
   using C = FfnRowsCfg<D, NW, CPS, NSLOT>;
@@ -268,13 +315,20 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   const unsigned ring_base = __builtin_amdgcn_readfirstlane(lds_addr(ringl));
 
   const int ntiles = (M + R - 1) / R;
-  const int NSL = F / (32 * CPS) + (OP ? 1 : 0);  // slots per tile (fused form: slot 0 = the out-projection)
-  const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int slice = SL ? (int)blockIdx.x % nslice : 0;
+  // chunk slots of a unit: slice s of n takes slots [s N / n, (s + 1) N / n) (uneven when n does not divide N)
+  const int slot_first = SL ? slice * (F / (32 * CPS)) / nslice : 0;
+  const int nchunk_slots = SL ? (slice + 1) * (F / (32 * CPS)) / nslice - slot_first : F / (32 * CPS);
+  const int NSL = nchunk_slots + (OP ? 1 : 0);  // slots per tile (fused form: slot 0 = the out-projection)
+  const int my_tiles = SL ? ((int)blockIdx.x / nslice < ntiles ? 1 : 0)
+                       : ONE ? ((int)blockIdx.x < ntiles ? 1 : 0)
+                             : ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * NSL;
   if (total == 0) return;  // (uniform over the workgroup)
 
+  const float* const ring_s = ring + (size_t)slot_first * C::SLOT_FLOATS;  // this unit's chunk slots
   auto slot_src = [&](int wslot) -> const float* {  // packed slot `wslot` of a tile's stream
-    return OP ? (wslot == 0 ? ringp : ring + (size_t)(wslot - 1) * C::SLOT_FLOATS) : ring + (size_t)wslot * C::SLOT_FLOATS;
+    return OP ? (wslot == 0 ? ringp : ring_s + (size_t)(wslot - 1) * C::SLOT_FLOATS) : ring_s + (size_t)wslot * C::SLOT_FLOATS;
   };
   auto issue_ring = [&](int wslot, int rslot) {  // packed slot `wslot` of the layer -> ring slot `rslot`
     const float* src = slot_src(wslot) + lane * 4;
@@ -285,7 +339,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   float4 xv[CTA][4], xrem[NRA];  // X rows (B operands of GEMM1 and the residual)
   f32x16 yacc[CTA];
   f32x4 yrem[NGA];
-  int tile = blockIdx.x;
+  int tile = SL ? (int)blockIdx.x / nslice : (int)blockIdx.x;
   int wnext = C::AHEAD % NSL;  // packed slot the next ring DMA fetches
   // The wave's 32 rows of `src` in ACCUMULATOR layout: lane (row m, half) holds columns 32 ct + 8 t + 4 half + (0..3) as
   // one float4 per (ct, t) -- B operands under the pack's k permutation, and residual rows.
@@ -546,10 +600,11 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
     }
     {
       float4 v[CTA][4], vr[NRA];
-      ln_rows<D>(yacc, yrem, xv, xrem, lnp, half, v, vr);
+      if (SL) raw_rows<D>(yacc, yrem, xv, xrem, lnp, half, slice == 0, v, vr);
+      else ln_rows<D>(yacc, yrem, xv, xrem, lnp, half, v, vr);
       const int row = tile * R + wave * 32 + m;
       if (row < M) {
-        float* yr = Y + (size_t)row * D;
+        float* yr = Y + ((size_t)(SL ? slice : 0) * M + row) * D;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -596,6 +651,81 @@ bool ffn_rows_fused_selected(int M, int D, int F) {
   return g_ffn_rows_fuse && g_ffn_rows_cps != 1 && g_ffn_rows_nw != 6 && ffn_rows_selected(M, D, F);
 }
 
+// y = LayerNorm2(sum over slices of the partial rows, in slice order): one row per 32 lanes (18 of them hold a float4 at
+// d_model 72), 8 rows per workgroup.  HBM-bound: (nslice + 1) D 4 bytes per row.
+template <int D>
+__global__ __launch_bounds__(256) void k_rows_reduce_ln(const float* __restrict__ P, int nslice, int M,
+                                                        const float* __restrict__ gam, const float* __restrict__ bet,
+                                                        float* __restrict__ Y) {
+  static_assert(D % 4 == 0 && D / 4 <= 32, "one float4 per lane of a 32-lane group");
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int j = threadIdx.x & 31;
+  if (row >= M) return;
+  const bool on = j < D / 4;
+  float4 a{0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    a = *reinterpret_cast<const float4*>(P + (size_t)row * D + 4 * j);
+    for (int sidx = 1; sidx < nslice; ++sidx) {
+      const float4 q = *reinterpret_cast<const float4*>(P + ((size_t)sidx * M + row) * D + 4 * j);
+      a.x += q.x, a.y += q.y, a.z += q.z, a.w += q.w;
+    }
+  }
+  float sum = (a.x + a.y) + (a.z + a.w);
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum * (1.0f / D);
+  const float dx = a.x - mean, dy = a.y - mean, dz = a.z - mean, dw = a.w - mean;
+  float ss = on ? fmaf(dw, dw, fmaf(dz, dz, fmaf(dy, dy, dx * dx))) : 0.f;
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+  if (on) {
+    const float4 g4 = *reinterpret_cast<const float4*>(gam + 4 * j), e4 = *reinterpret_cast<const float4*>(bet + 4 * j);
+    *reinterpret_cast<float4*>(Y + (size_t)row * D + 4 * j) =
+        float4{dx * rstd * g4.x + e4.x, dy * rstd * g4.y + e4.y, dz * rstd * g4.z + e4.z, dw * rstd * g4.w + e4.w};
+  }
+}
+
+int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuristic, -1 off, 2 / 4 / 8 / 16 forced (ffd_tune "rows_slices")
+
+// Mid-size M: (waves per workgroup, slices) of the sliced form, or false where another form is expected to be faster.
+// Estimate per launch (us, tools/ffn_rows_sweep.py at d_model 72, F 2048): out-projection slot + chunk slots at the
+// pace of NW / 4 waves per SIMD + launch / prologue / tile end, + the reduce launch; a unit per CU at most.
+bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
+  if (g_rows_slices < 0 || !g_ffn_rows || !g_ffn_rows_fuse || g_ffn_rows_cps == 1 || !ffn_rows_supported(D, F)) return false;
+  const int nslots = F / 64;
+  double best = 1e30;
+  int bnw = 0, bs = 0;
+  for (int nw = 8; nw <= 12; nw += 4) {
+    if (g_ffn_rows_nw && g_ffn_rows_nw != nw) continue;
+    const int tiles = cdiv(M, 32 * nw);
+    const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots, p_us = nw == 12 ? 10.0 : 7.0;
+    const int smax = num_cus() / tiles < nslots ? num_cus() / tiles : nslots;
+    for (int sl = 2; sl <= smax; ++sl) {
+      if (g_rows_slices > 0 && g_rows_slices != sl) continue;
+      const double t = p_us + cdiv(nslots, sl) * slot_us + 15.0 + 6.0 + 1.2e-4 * M * (sl + 1) * D * 4 / 1000.0;
+      if (t < best) best = t, bnw = nw, bs = sl;
+    }
+  }
+  if (!bs) return false;
+  if (g_rows_slices == 0) {
+    // what it competes with: the unsliced fused kernel where that is selected (full passes over the CUs), else the
+    // F-sliced k_ffn_ln forms + k_linear_res_ln (tools/sweep_mid.py: ~ 30 us + 6 ns per row)
+    double alt = 30.0 + 6.0e-3 * M;
+    if (ffn_rows_selected(M, D, F)) {
+      alt = 1e30;
+      for (int nw = 4; nw <= 12; nw += 4) {
+        const double loop = nw == 12 ? 392.0 : nw == 8 ? 271.0 : 146.0;
+        alt = fmin(alt, cdiv(cdiv(M, 32 * nw), num_cus()) * (loop + 10.0) + 15.0);
+      }
+    }
+    if (best > 0.97 * alt) return false;
+  }
+  *nw_out = bnw, *nslice_out = bs;
+  return true;
+}
+size_t rows_slice_floats(int M, int D, int nslice) { return (size_t)nslice * M * D; }
+
 struct RowsArgs {
   const float *X, *Rin;  // fused: attention output + layer input; else the FFN input (Rin unused)
   const LayerWeights* w;
@@ -603,6 +733,7 @@ struct RowsArgs {
   int M, F;
   bool fused;
   unsigned long long* stamp;
+  int nslice = 0;  // > 0: the sliced form (Y = the partial rows [nslice][M][D])
 };
 
 template <int D, int NW, int CPS, int NSLOT>
@@ -613,31 +744,48 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
   constexpr int per_cu_lds = (160 * 1024) / (FfnRowsCfg<D, NW, CPS, NSLOT>::LDS_FLOATS * 4);
   constexpr int per_cu = per_cu_lds < 12 / NW ? per_cu_lds : 12 / NW;
   const int slots = per_cu * num_cus();
-  const int grid = ntiles < slots ? ntiles : slots;
+  const int grid = a.nslice > 0 ? ntiles * a.nslice : ntiles < slots ? ntiles : slots;
   const LayerWeights& w = *a.w;
-#define FFD_ROWS_LAUNCH(PR, OP)                                                                                        \
-  hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, PR, OP>), dim3(grid), dim3(64 * NW), 0, s, a.X, a.Rin, w.ring,      \
-                     w.ring_op, w.b2, w.n2w, w.n2b, w.out_b, w.n1w, w.n1b, a.Y, a.M, a.F, a.stamp)
+#define FFD_ROWS_LAUNCH2(PR, OP, SL, ONE)                                                                              \
+  hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, PR, OP, SL, ONE>), dim3(grid), dim3(64 * NW), 0, s, a.X, a.Rin,     \
+                     w.ring, w.ring_op, w.b2, w.n2w, w.n2b, w.out_b, w.n1w, w.n1b, a.Y, a.M, a.F, a.nslice, a.stamp)
+#define FFD_ROWS_LAUNCH(PR, OP, SL)                                                                                    \
+  do {                                                                                                                 \
+    if constexpr (!(SL)) {                                                                                             \
+      if (grid == ntiles) FFD_ROWS_LAUNCH2(PR, OP, false, true); else FFD_ROWS_LAUNCH2(PR, OP, false, false);          \
+    } else {                                                                                                           \
+      FFD_ROWS_LAUNCH2(PR, OP, true, false);                                                                           \
+    }                                                                                                                  \
+  } while (0)
   if constexpr (CPS == 2 && NSLOT == 3 && NW != 6) {
     if (a.fused) {
-      if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, true); else FFD_ROWS_LAUNCH(0, true);
+      if constexpr (NW >= 8) {
+        if (a.nslice > 0) {
+          if (a.nslice * ntiles > slots || a.nslice > a.F / 64) return hipErrorInvalidValue;
+          if (g_ffn_rows_prio) FFD_ROWS_LAUNCH(1, true, true); else FFD_ROWS_LAUNCH(0, true, true);
+          return hipGetLastError();
+        }
+      }
+      if (a.nslice > 0) return hipErrorInvalidValue;
+      if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, true, false); else FFD_ROWS_LAUNCH(0, true, false);
       return hipGetLastError();
     }
   }
-  if (a.fused) return hipErrorInvalidValue;
-  if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, false); else FFD_ROWS_LAUNCH(0, false);
+  if (a.fused || a.nslice > 0) return hipErrorInvalidValue;
+  if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, false, false); else FFD_ROWS_LAUNCH(0, false, false);
 #undef FFD_ROWS_LAUNCH
+#undef FFD_ROWS_LAUNCH2
   return hipGetLastError();
 }
 
-static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s) {
+static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int nw_forced = 0) {
   if (a.M <= 0) return hipSuccess;
   if (!ffn_rows_supported(D, a.F) || a.w->ring == nullptr || (a.fused && a.w->ring_op == nullptr)) return hipErrorInvalidValue;
   // Waves per workgroup: a tile is 32 NW rows and every CU walks ceil(tiles / CUs) of them at NW / 4 waves per SIMD.
   // Pick the NW with the least estimated time = passes x waves per SIMD / measured main-loop efficiency
   // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
   // SIMD); ties go to more waves (the weights are then streamed fewer times).  ffd_tune "ffn_rows_nw" forces it.
-  int nw = g_ffn_rows_nw;
+  int nw = nw_forced ? nw_forced : g_ffn_rows_nw;
   if (nw != 4 && nw != 6 && nw != 8 && nw != 12) {
     const double eff[3] = {0.85, 0.915, 0.938};
     double best = 0.0;
@@ -670,6 +818,18 @@ hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int 
 hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const LayerWeights& w, float* Y, int M, int D,
                                  int F, hipStream_t s, unsigned long long* stamp) {
   return launch_rows_any(RowsArgs{attn, Rin, &w, Y, M, F, true, stamp}, D, s);
+}
+
+// The same for mid-size M as tiles x nslice units + the reduce / LN2 launch; P holds nslice x M x D floats.
+hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, const LayerWeights& w, float* P, float* Y,
+                                        int M, int D, int F, int nw, int nslice, hipStream_t s) {
+  if (D != 72 || nslice < 2) return hipErrorInvalidValue;
+  RowsArgs a{attn, Rin, &w, P, M, F, true, nullptr};
+  a.nslice = nslice;
+  const hipError_t e = launch_rows_any(a, D, s, nw);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_rows_reduce_ln<72>, dim3(cdiv(M, 8)), dim3(256), 0, s, P, nslice, M, w.n2w, w.n2b, Y);
+  return hipGetLastError();
 }
 
 }  // namespace ffd

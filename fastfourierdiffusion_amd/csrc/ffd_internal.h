@@ -143,6 +143,12 @@ size_t ffn_ring_oproj_floats(int D);
 hipError_t launch_pack_oproj_ring(const float* Wo, float* out, int D, hipStream_t s);
 hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const LayerWeights& w, float* Y, int M, int D,
                                  int F, hipStream_t s, unsigned long long* stamp = nullptr);
+// mid-size M: the fused kernel over tiles x slices of the hidden dimension + a reduce / LN2 launch
+extern int g_rows_slices;
+bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out);
+size_t rows_slice_floats(int M, int D, int nslice);
+hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, const LayerWeights& w, float* P, float* Y,
+                                        int M, int D, int F, int nw, int nslice, hipStream_t s);
 // Small M (the reference harness's batch 1): out-proj + LN1 + FFN + LN2 as two launches with F split over NS
 // workgroups per 16-row tile (ffd_small.hip).  small_path_splits returns 0 when the large-M kernels should run.
 int small_path_splits(int M, int D, int F);

@@ -298,6 +298,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_rows_fuse" = 1 | 0                    out-projection + residual + LN1 inside k_ffn_rows (one more ring slot per
  *                                              tile; two-chunk slots only) or k_linear_res_ln in front of it;
  *   "ffn_rows_prio" = 1 | 0                    descending wave priority through a barrier interval of k_ffn_rows;
+ *   "rows_slices" = 0 (heuristic) | -1 | 2..32 mid-size M: the fused kernel over tiles x slices of the hidden dimension
+ *                                              (one unit per CU) + a reduce / LN2 launch; -1 = never, n = n slices forced;
  *   "ffn_persist" = 1 | 0 | n                  k_ffn_ln at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
  *   "small_path" = 1 | 0                       small M: out-proj + LN1 + FFN + LN2 with F split over up to 16 workgroups per
  *                                              16-row tile and a reduce + LN2 launch (ffd_small.hip); "small_wgs" = n: most

@@ -1314,6 +1314,35 @@ def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     assert rel_err(old.cpu(), ref.cpu()) < 2e-6
 
 
+def test_rows_sliced_form_agrees_with_the_other_forms(ffd):
+    """Mid-size batches run the fused out-proj + FFN kernel over tiles x slices of the hidden dimension (a unit per CU)
+    and add the slices' partial rows in order in a reduce / LN2 launch: every (waves, slices) choice agrees with the
+    forms it replaces to rounding, is deterministic, and a sample's result does not depend on the batch around it."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    for B in (24, 96, 130):
+        x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4242 + B))).cuda()
+        assert lib.ffd_tune(b"rows_slices", -1) == 0
+        ref = m(batch_of(x, 0.4))
+        for nw in (8, 12):
+            for S in (2, 3, 5, 8, 16):
+                if -(-B * c["L"] // (32 * nw)) * S > 256:
+                    continue
+                assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"rows_slices", S) == 0
+                a = m(batch_of(x, 0.4))
+                b = m(batch_of(x, 0.4))
+                assert torch.equal(a, b), (B, nw, S)
+                assert rel_err(a.cpu(), ref.cpu()) < 2e-6, (B, nw, S)
+                part = m(batch_of(x[: B // 2].contiguous(), 0.4))  # other tile / unit assignment
+                assert rel_err(part.cpu(), a[: B // 2].cpu()) < 2e-6, (B, nw, S)
+        assert lib.ffd_tune(b"reset", 0) == 0
+        auto = m(batch_of(x, 0.4))
+        assert rel_err(auto.cpu(), ref.cpu()) < 2e-6, B
+
+
 def test_ffn_ln_persistent_grid_equals_one_workgroup_per_tile(ffd):
     """k_ffn_ln (the F-split workgroup; large M of every d_model without a k_ffn_rows instance, selected here with
     ffd_tune "ffn_rows" = 0) walks its tiles with a persistent grid: bit-identical with one workgroup per tile and with

@@ -25,26 +25,33 @@ dev = torch.device("cuda", 0)
 lib = N.lib()
 s = N.current_stream_ptr(dev)
 g = torch.Generator(device=dev).manual_seed(1)
-x = torch.randn(B, L, Cn, device=dev, generator=g)
-y = torch.empty_like(x)
-z = torch.randn(B, L, Cn, device=dev, generator=g)
+# NP buffer pairs in rotation: one launch's working set is 2-3 x 134 MB at the default size, so with a single pair a
+# good part of every read came out of the 256 MiB Infinity Cache; four pairs (> 1 GB) are all evicted before reuse
+NP = int(os.environ.get("HBM_PAIRS", "4"))
+xs = [torch.randn(B, L, Cn, device=dev, generator=g) for _ in range(NP)]
+ys = [torch.empty_like(xs[0]) for _ in range(NP)]
 Gh = (C.c_float * L)()
 lib.ffd_host_noise_scaling(L, 1, Gh)
 Gd = torch.tensor(list(Gh), device=dev)
 sde = N.SdeDesc(0, 0, 0.1, 20.0)
-work = torch.empty(B * Cn * (L // 2 + 1) + 4, device=dev)
+works = [torch.empty(B * Cn * (L // 2 + 1) + 4, device=dev) for _ in range(NP)]
 n = B * L * Cn
-for _ in range(iters):
+for i in range(iters * NP):
+    x, y = xs[i % NP], ys[i % NP]
     assert lib.ffd_dft(x.data_ptr(), y.data_ptr(), B, L, Cn, s) == 0
+for i in range(iters * NP):
+    x, y = xs[i % NP], ys[i % NP]
     assert lib.ffd_idft(y.data_ptr(), x.data_ptr(), B, L, Cn, s) == 0
-for i in range(iters):
+for i in range(iters * NP):
+    x, y = xs[i % NP], ys[i % NP]
     assert lib.ffd_sde_step(C.byref(sde), x.data_ptr(), y.data_ptr(), Gd.data_ptr(), 0.5, 1e-3, None, 42, 0, i, B, L, Cn, s) == 0
-for i in range(iters):
-    assert lib.ffd_prior(C.byref(sde), x.data_ptr(), None, Gd.data_ptr(), 42, 0, B, L, Cn, s) == 0
-for i in range(iters):
-    assert lib.ffd_fresca(y.data_ptr(), x.data_ptr(), work.data_ptr(), B, L, Cn, 1.0, 1.5, 0.5, 0, s) == 0
-for i in range(iters):
-    assert lib.ffd_fresca(y.data_ptr(), x.data_ptr(), work.data_ptr(), B, L, Cn, 1.0, 1.5, 0.5, 1, s) == 0
+for i in range(iters * NP):
+    assert lib.ffd_prior(C.byref(sde), xs[i % NP].data_ptr(), None, Gd.data_ptr(), 42, 0, B, L, Cn, s) == 0
+for mode in (0, 1):
+    for i in range(iters * NP):
+        x, y, work = xs[i % NP], ys[i % NP], works[i % NP]
+        assert lib.ffd_fresca(y.data_ptr(), x.data_ptr(), work.data_ptr(), B, L, Cn, 1.0, 1.5, 0.5, mode, s) == 0
+x = xs[0]
 torch.cuda.synchronize()
 
 # embed / unembed / out-proj+LN1 through one score evaluation (and the sampling loop's fused tail)

@@ -25,17 +25,20 @@ def run(B):
         lib.ffd_kernel_timing_get(ctx.handle, cls, C.byref(ms), C.byref(n))
         out[cls] = ms.value * 1e3  # average per launch, us
     return out
-for B in (16, 32, 50, 64, 96, 128, 200, 256, 320, 384, 512, 768):
+Bs = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (16, 32, 50, 64, 96, 128, 200, 256, 320, 384, 512, 768)
+# FFN class + out-projection, us per layer: "old" = the round-2 forms (sliced rows off, k_ffn_rows unfused off), "auto" =
+# today's heuristics, "nw:S" = the sliced fused kernel forced (waves per workgroup : slices of the hidden dimension)
+for B in Bs:
     row = []
-    for name, tunes in (("mb1", {"small_path": 0, "mid_path": 0, "ffn_mb": 1}), ("mb2", {"small_path": 0, "mid_path": 0, "ffn_mb": 2}),
-                        ("mb4", {"small_path": 0, "mid_path": 0, "ffn_mb": 4}),
-                        ("pair16", {"small_path": 1, "small_wgs": 0, "mid_path": 0, "ffn_mb": 0}),
-                        ("part2", {"small_path": 0, "mid_path": 2, "ffn_mb": 0}),
-                        ("part4", {"small_path": 0, "mid_path": 4, "ffn_mb": 0}),
-                        ("part8", {"small_path": 0, "mid_path": 8, "ffn_mb": 0}),
-                        ("auto", {"small_path": 1, "small_wgs": 0, "mid_path": 1, "ffn_mb": 0})):
+    variants = [("old", {"rows_slices": -1, "ffn_rows_fuse": 0}), ("auto", {})]
+    for nw in (12, 8):
+        for S in (2, 3, 4, 5, 6, 8):
+            if -(-B * L // (32 * nw)) * S <= 256:
+                variants.append((f"{nw}:{S}", {"ffn_rows_nw": nw, "rows_slices": S}))
+    for name, tunes in variants:
+        lib.ffd_tune(b"reset", 0)
         for k, v in tunes.items():
-            lib.ffd_tune(k.encode(), v)
+            assert lib.ffd_tune(k.encode(), v) == 0, k
         t = run(B)
         row.append(f"{name} {t[N.K_FFN] + t[N.K_OUTPROJ]:.1f}")
     print(f"B={B} M={B*L}: " + "  ".join(row) + f"   attn {t[N.K_ATTN]:.1f}", flush=True)
