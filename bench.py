@@ -287,7 +287,7 @@ def roofline_entry(lib, ctx, N, cls, B, cache_hit, traffic_tab, key):
     else:
         ach, peak, unit = by.value / sec / 1e9, PEAK_HBM_GBS, "GB/s"
     return {"kernel": name, "bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak, "unit": unit,
-            "frac": ach / peak, "traffic": traffic_tab.get(f"{key}:{name}"),
+            "frac": ach / peak, "traffic": traffic_tab.get(f"{key}:{name}", traffic_tab.get(f"{key}:{name.split('<')[0].split(' ')[0]}")),
             "flops_per_launch": fl.value, "algorithmic_bytes_per_launch": by.value, "ms_per_launch": ms.value,
             "launches_timed": cnt.value}
 

@@ -187,9 +187,9 @@ int ffd_tune(const char* key, int value) {
   if (!key) return FFD_ERR_INVALID;
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
-    g_ffn_rows_cps = 0, g_ffn_rows_prio = 1, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
+    g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
-    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_fuse_tail = 1;
+    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_fuse_tail = 1;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
@@ -253,12 +253,8 @@ int ffd_tune(const char* key, int value) {
     g_rows_slices = value;
     return FFD_OK;
   }
-  if (!strcmp(key, "ffn_rows_prio")) {
-    g_ffn_rows_prio = value ? 1 : 0;
-    return FFD_OK;
-  }
   if (!strcmp(key, "ffn_rows_nw")) {
-    if (value != 0 && value != 4 && value != 6 && value != 8 && value != 12) return FFD_ERR_INVALID;
+    if (value != 0 && value != 4 && value != 8 && value != 12) return FFD_ERR_INVALID;
     g_ffn_rows_nw = value;
     return FFD_OK;
   }
@@ -274,6 +270,15 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "lstm_wave")) {  // LSTM layers as a wavefront below the k_lstm_mfma crossover: 1 | 0 | 2 (every batch)
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_lstm_wave = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_wave_persist")) {  // k_lstm_wave workgroups walk their tile's layers (1) | one launch per layer group (0)
+    g_lstm_wave_persist = value ? 1 : 0;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_wave_per")) {  // at most this many layers in flight (0 = as many as the CUs hold)
+    if (value < 0 || value > 16) return FFD_ERR_INVALID;
+    g_lstm_wave_per = value;
     return FFD_OK;
   }
   if (!strcmp(key, "lstm_mfma_s")) {  // 16-sample tiles per workgroup of that kernel (0 = by batch)

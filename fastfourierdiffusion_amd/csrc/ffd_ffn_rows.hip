@@ -638,7 +638,6 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
 int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
 int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
 int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
-int g_ffn_rows_prio = 1;  // descending wave priority through a barrier interval (ffd_tune "ffn_rows_prio")
 int g_ffn_rows_fuse = 1;  // out-projection + LN1 inside the kernel (ffd_tune "ffn_rows_fuse"; two-chunk slots only)
 
 bool ffn_rows_supported(int D, int F) { return D == 72 && F % 64 == 0 && F >= 64; }
@@ -648,7 +647,7 @@ bool ffn_rows_selected(int M, int D, int F) {
 }
 // the fused form (out-proj + LN1 + FFN + LN2 in one launch) is taken where k_ffn_rows is, with two-chunk ring slots
 bool ffn_rows_fused_selected(int M, int D, int F) {
-  return g_ffn_rows_fuse && g_ffn_rows_cps != 1 && g_ffn_rows_nw != 6 && ffn_rows_selected(M, D, F);
+  return g_ffn_rows_fuse && g_ffn_rows_cps != 1 && ffn_rows_selected(M, D, F);
 }
 
 // y = LayerNorm2(sum over slices of the partial rows, in slice order): one row per 32 lanes (18 of them hold a float4 at
@@ -746,6 +745,7 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
   const int slots = per_cu * num_cus();
   const int grid = a.nslice > 0 ? ntiles * a.nslice : ntiles < slots ? ntiles : slots;
   const LayerWeights& w = *a.w;
+  constexpr int PRV = NW > 4 ? 1 : 0;  // descending wave priority through a barrier interval: with > 1 wave per SIMD
 #define FFD_ROWS_LAUNCH2(PR, OP, SL, ONE)                                                                              \
   hipLaunchKernelGGL((k_ffn_rows<D, NW, CPS, NSLOT, PR, OP, SL, ONE>), dim3(grid), dim3(64 * NW), 0, s, a.X, a.Rin,     \
                      w.ring, w.ring_op, w.b2, w.n2w, w.n2b, w.out_b, w.n1w, w.n1b, a.Y, a.M, a.F, a.nslice, a.stamp)
@@ -757,22 +757,22 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
       FFD_ROWS_LAUNCH2(PR, OP, true, false);                                                                           \
     }                                                                                                                  \
   } while (0)
-  if constexpr (CPS == 2 && NSLOT == 3 && NW != 6) {
+  if constexpr (CPS == 2 && NSLOT == 3) {
     if (a.fused) {
       if constexpr (NW >= 8) {
         if (a.nslice > 0) {
           if (a.nslice * ntiles > slots || a.nslice > a.F / 64) return hipErrorInvalidValue;
-          if (g_ffn_rows_prio) FFD_ROWS_LAUNCH(1, true, true); else FFD_ROWS_LAUNCH(0, true, true);
+          FFD_ROWS_LAUNCH(PRV, true, true);
           return hipGetLastError();
         }
       }
       if (a.nslice > 0) return hipErrorInvalidValue;
-      if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, true, false); else FFD_ROWS_LAUNCH(0, true, false);
+      FFD_ROWS_LAUNCH(PRV, true, false);
       return hipGetLastError();
     }
   }
   if (a.fused || a.nslice > 0) return hipErrorInvalidValue;
-  if (g_ffn_rows_prio && NW > 4) FFD_ROWS_LAUNCH(1, false, false); else FFD_ROWS_LAUNCH(0, false, false);
+  FFD_ROWS_LAUNCH(PRV, false, false);
 #undef FFD_ROWS_LAUNCH
 #undef FFD_ROWS_LAUNCH2
   return hipGetLastError();
@@ -786,7 +786,7 @@ static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int n
   // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
   // SIMD); ties go to more waves (the weights are then streamed fewer times).  ffd_tune "ffn_rows_nw" forces it.
   int nw = nw_forced ? nw_forced : g_ffn_rows_nw;
-  if (nw != 4 && nw != 6 && nw != 8 && nw != 12) {
+  if (nw != 4 && nw != 8 && nw != 12) {
     const double eff[3] = {0.85, 0.915, 0.938};
     double best = 0.0;
     for (int i = 2; i >= 0; --i) {
@@ -797,8 +797,6 @@ static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int n
   }
   const int cps = g_ffn_rows_cps == 1 ? 1 : 2;  // 32-unit chunks per ring slot = per barrier (ffd_tune "ffn_rows_cps")
   switch (nw * 10 + cps) {
-    case 61:
-    case 62: return launch_rows_cfg<72, 6, 1, 3>(a, s);  // two workgroups (two rings) per CU
     case 41: return launch_rows_cfg<72, 4, 1, 4>(a, s);
     case 42: return launch_rows_cfg<72, 4, 2, 3>(a, s);
     case 81: return launch_rows_cfg<72, 8, 1, 4>(a, s);

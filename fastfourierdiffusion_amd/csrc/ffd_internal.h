@@ -136,7 +136,7 @@ size_t ffn_ring_floats(int D, int F);
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
 hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                            unsigned long long* stamp = nullptr);
-extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_prio, g_ffn_rows_fuse;
+extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_fuse;
 // out-proj + LN1 + FFN + LN2 in one launch (the fused form of k_ffn_rows); Y must not alias attn / Rin
 bool ffn_rows_fused_selected(int M, int D, int F);
 size_t ffn_ring_oproj_floats(int D);
@@ -212,7 +212,7 @@ hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const 
 // batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
 // prog: >= 16 * ceil(B / 16) ints of device scratch (progress words, cleared by the launcher)
 bool lstm_wave_selected(int B, int D);
-extern int g_lstm_wave;
+extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per;
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
                             int B, int L, int D, int* prog, hipStream_t s);
 

@@ -418,7 +418,12 @@ struct LstmWaveArgs {
 
 template <int D>
 __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, LstmWaveArgs wa, int n_layers, int n_tiles,
-                                                      int B, int L, int* __restrict__ prog) {
+                                                      int per, int B, int L, int* __restrict__ prog) {
+  // The grid is `per` layers x n_tiles workgroups, all resident.  Workgroup (layer l0, tile) runs layer l0 and then, on
+  // the same CU, layers l0 + per, l0 + 2 per, ... of its tile: when it finishes a layer the layer below its next one
+  // (started per - 1 layers after its own) is ~7 (per - 1) steps from its end, so the next assignment runs without
+  // waiting -- n_layers x n_tiles workgroup-runs go through the CUs as a continuous stream instead of
+  // ceil(n_layers / per) launches that each drain.  Every poll is on a workgroup that is resident: no deadlock.
   // Eight waves, two per SIMD, in two roles (the cell step of k_lstm_mfma split in two):
   //   waves 0-3 (recurrent): acc = gx_t image; acc += W_hh h_{t-1}^T (W_hh fragments in VGPRs); lane-local cell
   //                          update; h_t -> LDS.  Only this is on the recurrence's critical path.
@@ -444,14 +449,15 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   // recurrent wave w (wave w + 4) takes the mirrored share, so that every SIMD carries 9 tiles per step
   const int wave = recur ? wave8 : 7 - wave8;
   const int tg = threadIdx.x & 255;
-  const int layer = blockIdx.x / n_tiles, tile = blockIdx.x - layer * n_tiles;  // (uniform)
+  const int layer0 = blockIdx.x / n_tiles, tile = blockIdx.x - layer0 * n_tiles;  // (uniform)
+  const int j = lane & 15, q = lane >> 4;
+  const int t0 = wave * (NT / 4) + min(wave, NT % 4);
+  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
+  for (int layer = layer0; layer < n_layers; layer += per) {
   const float* wsrc = recur ? wa.whh[layer] : wa.wih[layer];
   const float* bsum = wa.bsum[layer];
   int* my_prog = prog + layer * n_tiles + tile;
   const int* up_prog = layer > 0 ? prog + (layer - 1) * n_tiles + tile : nullptr;
-  const int j = lane & 15, q = lane >> 4;
-  const int t0 = wave * (NT / 4) + min(wave, NT % 4);
-  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
 
   // this role's weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]); row order inside a
   // 16-row tile is (unit, gate) = (i >> 2, i & 3), see k_lstm_mfma
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
     }
     __syncthreads();  // h_{L-1} complete
     __syncthreads();  // (the input role's last stores have left)
-    return;
+    continue;         // next assignment (both roles pass the same L + 4 barriers per layer)
   }
 
   // -------------------------------------------------------------------- input role
@@ -631,10 +637,13 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tg == 0) __hip_atomic_store(my_prog, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }  // assignments
 }
 
 constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5 * 16 * (D + 2)) * 4; }
 
+int g_lstm_wave_persist = 1;  // workgroups walk their tile's layers (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
+int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
 int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
 
 bool lstm_wave_selected(int B, int D) {
@@ -652,18 +661,25 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
     if (e != hipSuccess) return e;
   }
   const int n_tiles = cdiv(B, 16);
-  int per = num_cus() / n_tiles;  // layers per launch: every workgroup of a launch is resident
+  int per = num_cus() / n_tiles;  // layers in flight: every workgroup of a launch is resident
+  if (g_lstm_wave_per > 0 && g_lstm_wave_per < per) per = g_lstm_wave_per;
   if (per > 16) per = 16;
   if (per < 1) return hipErrorInvalidValue;
-  for (int l0 = 0; l0 < NL; l0 += per) {
-    const int nl = NL - l0 < per ? NL - l0 : per;
-    LstmWaveArgs wa{};
-    for (int i = 0; i < nl; ++i) wa.wih[i] = wih[l0 + i], wa.whh[i] = whh[l0 + i], wa.bsum[i] = bsum[l0 + i];
-    hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)nl * n_tiles, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_lstm_wave<D>), dim3(nl * n_tiles), dim3(512), lds, s, x, wa, nl, n_tiles, B, L, prog);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+  // up to 16 layers per launch (the argument block); within a launch the workgroups walk their tile's layers
+  for (int l0 = 0; l0 < NL; l0 += 16) {
+    const int nl = NL - l0 < 16 ? NL - l0 : 16;
+    const int pl = g_lstm_wave_persist ? (per < nl ? per : nl) : per;
+    for (int l1 = 0; l1 < nl; l1 += (g_lstm_wave_persist ? nl : per)) {
+      const int n1 = g_lstm_wave_persist ? nl : (nl - l1 < per ? nl - l1 : per);
+      LstmWaveArgs wa{};
+      for (int i = 0; i < n1; ++i) wa.wih[i] = wih[l0 + l1 + i], wa.whh[i] = whh[l0 + l1 + i], wa.bsum[i] = bsum[l0 + l1 + i];
+      hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)n1 * n_tiles, s);
+      if (e != hipSuccess) return e;
+      const int first = pl < n1 ? pl : n1;
+      hipLaunchKernelGGL((k_lstm_wave<D>), dim3(first * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, first, B, L, prog);
+      e = hipGetLastError();
+      if (e != hipSuccess) return e;
+    }
   }
   return hipSuccess;
 }

@@ -292,12 +292,10 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
  *                                              every M where the small- / mid-batch forms are off (test suite);
- *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave); 6 = two
- *                                              6-wave workgroups per CU (does not co-reside on this chip: tests only);
+ *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave);
  *   "ffn_rows_cps" = 0 | 2 | 1                 32-unit chunks per ring slot (= per barrier) of k_ffn_rows (default 2);
  *   "ffn_rows_fuse" = 1 | 0                    out-projection + residual + LN1 inside k_ffn_rows (one more ring slot per
  *                                              tile; two-chunk slots only) or k_linear_res_ln in front of it;
- *   "ffn_rows_prio" = 1 | 0                    descending wave priority through a barrier interval of k_ffn_rows;
  *   "rows_slices" = 0 (heuristic) | -1 | 2..32 mid-size M: the fused kernel over tiles x slices of the hidden dimension
  *                                              (one unit per CU) + a reduce / LN2 launch; -1 = never, n = n slices forced;
  *   "ffn_persist" = 1 | 0 | n                  k_ffn_ln at large M: persistent grid (n x resident workgroups) or one workgroup per tile;
@@ -318,8 +316,11 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
  *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
  *   "lstm_wave" = 1 | 0 | 2                    LSTM below that batch: all layers as a wavefront of (16-sample tile, layer)
- *                                              workgroups in one launch per layer group (k_lstm_wave), or the per-layer
- *                                              kernels (0); 2 = at every batch (test suite);
+ *                                              workgroups (k_lstm_wave), or the per-layer kernels (0); 2 = at every
+ *                                              batch (test suite);
+ *   "lstm_wave_persist" = 1 | 0                its workgroups walk their tile's layers l0, l0 + per, ... in one launch, or
+ *                                              one launch per group of `per` layers; "lstm_wave_per" = n: at most n
+ *                                              layers in flight (0 = as many as the CUs hold; tests);
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;

@@ -1033,12 +1033,19 @@ def test_kernel_timing_and_work_accounting(ffd):
         N.check(ctx.lib.ffd_kernel_timing_get(ctx.handle, cls, C.byref(ms), C.byref(n)), ctx.handle, "get")
         counts[cls] = n.value
         assert (ms.value > 0) == (n.value > 0)
-    assert counts[N.K_FFN] == counts[N.K_ATTN] == counts[N.K_OUTPROJ] == 3 * NL
+    assert counts[N.K_FFN] == counts[N.K_ATTN] == 3 * NL
+    assert counts[N.K_OUTPROJ] == 0  # at this size the out-projection + LN1 run inside the FFN kernel
     assert counts[N.K_EMBED] == 3 and counts[N.K_LSTM_REC] == 0
     assert counts[N.K_SDE] == 3  # the unembed may be fused into it
     fl, by = C.c_double(), C.c_double()
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_rows<oproj>"
+    assert fl.value == 4.0 * 512 * L * d * F + 2.0 * 512 * L * d * d  # 56.47 + 0.99 GFLOP at the ECG bench shape
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_OUTPROJ, 512, 0, C.byref(fl), C.byref(by)) is None
+    assert ctx.lib.ffd_tune(b"ffn_rows_fuse", 0) == 0
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 512, 0, C.byref(fl), C.byref(by)) == b"k_ffn_rows"
-    assert fl.value == 4.0 * 512 * L * d * F  # 56.47 GFLOP at the ECG bench shape
+    assert fl.value == 4.0 * 512 * L * d * F
+    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_OUTPROJ, 512, 0, C.byref(fl), C.byref(by)) == b"k_linear_res_ln"
+    assert ctx.lib.ffd_tune(b"reset", 0) == 0
     # the sampling loop unembeds inside the step kernel: hidden row + x in, x out
     assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_SDE, 512, 0, C.byref(fl), C.byref(by)).startswith(b"k_unembed_mfma")
     assert by.value == 4.0 * 512 * L * (d + 2 * Cn)
@@ -1167,6 +1174,15 @@ def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
         n = min(2, B)
         ref = O.lstm_score_forward(x[:n], torch.full((n,), 0.45, dtype=torch.float32), sd, c["NL"])
         assert rel_err(out[:n], ref) < TOL_SCORE, B
+        if B in (37, 512):
+            # a workgroup walks its tile's layers l0, l0 + per, ...: the same bits as one launch per layer group, and
+            # for any number of layers in flight
+            from fastfourierdiffusion_amd import _native as N
+            lib = N.lib()
+            for per, persist in ((0, 0), (1, 1), (2, 1), (3, 1), (3, 0)):
+                assert lib.ffd_tune(b"lstm_wave_per", per) == 0 and lib.ffd_tune(b"lstm_wave_persist", persist) == 0
+                assert torch.equal(m(batch_of(x.cuda(), 0.45)).cpu(), out), (B, per, persist)
+            assert lib.ffd_tune(b"reset", 0) == 0
 
 
 @pytest.fixture
@@ -1279,8 +1295,8 @@ def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     """The FFN at large M is k_ffn_rows: row-owning waves (32 rows each, whole hidden dimension) under a CU-shared LDS
     weight ring; by default the out-projection + LN1 run inside it too, from one more ring slot (two-chunk slots).
     Which wave of which workgroup owns a row, and how many chunks a ring slot holds, must not show in the result: the
-    ECG B = 512 score is bit-identical for 4 / 6 / 8 / 12 waves per workgroup (tiles of 128 / 192 / 256 / 384 rows;
-    6 waves = two workgroups with a ring each per CU) and for one or two chunks per slot in the unfused form, and for
+    ECG B = 512 score is bit-identical for 4 / 8 / 12 waves per workgroup (tiles of 128 / 256 / 384 rows) and for one or
+    two chunks per slot in the unfused form, and for
     4 / 8 / 12 waves in the fused form; fused and unfused agree to rounding (other k order in the out-projection); a
     ragged last tile (M = 513 * 187 rows) stays finite and independent; the F-split kernel it replaces (k_ffn_ln,
     other summation order) agrees to rounding."""
@@ -1291,7 +1307,7 @@ def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     lib = N.lib()
     x = torch.from_numpy(next(synthetic.noise_stream((513, c["L"], c["C"]), 1, 909))).cuda()
     refs = {}
-    for fuse, cfgs in ((0, ((0, 0), (4, 1), (4, 2), (6, 1), (8, 1), (8, 2), (12, 1), (12, 2))),
+    for fuse, cfgs in ((0, ((0, 0), (4, 1), (4, 2), (8, 1), (8, 2), (12, 1), (12, 2))),
                        (1, ((0, 0), (4, 2), (8, 2), (12, 2)))):
         outs = {}
         for nw, cps in cfgs:

@@ -21,7 +21,6 @@ for cfg in cfgs:
   assert lib.ffd_tune(b"ffn_rows_fuse", fuse) == 0
   for dbg in dbgs:
     assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_cps", mb) == 0
-    assert lib.ffd_tune(b"ffn_rows_prio", prio) == 0
     ms = C.c_float(); best = 1e9
     for _ in range(3):
         N.check(lib.ffd_bench_ffn(ctx.handle, B, 30, C.byref(ms), s), ctx.handle)
@@ -32,7 +31,7 @@ for cfg in cfgs:
     N.check(lib.ffd_probe_ffn_clock(ctx.handle, B, 0.5, C.byref(ghz), C.byref(us), raw, cap, C.byref(n), s), ctx.handle)
     r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 8)[: n.value].astype(np.float64)
     loop_us = float(np.median((r[:, 4] - r[:, 3]) * 0.01))
-    wps = {4: 1, 8: 2, 12: 3, 6: 3}[nw]  # waves per SIMD (nw = 6: two workgroups per CU)
+    wps = {4: 1, 8: 2, 12: 3}[nw]  # waves per SIMD
     mf = (68 * 64 + (0 if dbg & 1 else 32 * 8)) * 64 * wps  # MFMA issue cycles per SIMD and tile (32 rows per wave)
     out.append({"nw": nw, "mb": mb, "prio": prio, "fuse": fuse, "kernel_us": round(best, 1), "ghz": round(ghz.value, 3),
                 "tile_loop_us": round(loop_us, 1), "loop_eff": round(mf / (loop_us * ghz.value * 1e3), 3),
