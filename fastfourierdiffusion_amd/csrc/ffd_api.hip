@@ -82,6 +82,8 @@ struct ffd_ctx {
   float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
   int* lstm_prog = nullptr;  // progress words of the LSTM layer wavefront
   size_t lstm_prog_ints = 0;
+  float* lstm_state = nullptr;  // (tile, layer) state blocks of the time-chunked wavefront
+  size_t lstm_state_floats = 0;
   float* ffn_part = nullptr;  // partial Y tiles of the small-M split FFN
   size_t ffn_part_floats = 0;
   // FreSca (sampler-level)
@@ -189,7 +191,7 @@ int ffd_tune(const char* key, int value) {
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
-    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_fuse_tail = 1;
+    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
@@ -274,6 +276,11 @@ int ffd_tune(const char* key, int value) {
   }
   if (!strcmp(key, "lstm_wave_persist")) {  // k_lstm_wave workgroups walk their tile's layers (1) | one launch per layer group (0)
     g_lstm_wave_persist = value ? 1 : 0;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_wave_chunk")) {  // cell steps per unit of the time-shared wavefront: 0 = by the pass count, 1 = never, even n = forced
+    if (value < 0 || (value > 1 && (value & 1)) || value > 1024) return FFD_ERR_INVALID;
+    g_lstm_wave_chunk = value;
     return FFD_OK;
   }
   if (!strcmp(key, "lstm_wave_per")) {  // at most this many layers in flight (0 = as many as the CUs hold)
@@ -678,7 +685,12 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       }
       const float *wih[64], *whh[64], *bs[64];
       for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].wih, whh[i] = ctx->lstm[i].whh, bs[i] = ctx->lstm[i].bsum;
-      TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0, wih, whh, bs, m.num_layers, B, L, d, ctx->lstm_prog, s));
+      const size_t need_st = lstm_wave_state_floats(B, d, m.num_layers);
+      if (need_st > ctx->lstm_state_floats) {
+        if (int rc = dev_regrow(ctx, &ctx->lstm_state, need_st)) return rc;
+        ctx->lstm_state_floats = need_st;
+      }
+      TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0, wih, whh, bs, m.num_layers, B, L, d, ctx->lstm_prog, ctx->lstm_state, s));
     } else
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];

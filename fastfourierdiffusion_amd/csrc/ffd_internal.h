@@ -212,9 +212,10 @@ hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const 
 // batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
 // prog: >= 16 * ceil(B / 16) ints of device scratch (progress words, cleared by the launcher)
 bool lstm_wave_selected(int B, int D);
-extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per;
+extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk;
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
-                            int B, int L, int D, int* prog, hipStream_t s);
+                            int B, int L, int D, int* prog, float* state, hipStream_t s);
+size_t lstm_wave_state_floats(int B, int D, int NL);
 
 hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,
                         int M, int N, int K, int relu, hipStream_t s);

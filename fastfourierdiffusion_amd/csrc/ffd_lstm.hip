@@ -416,14 +416,21 @@ struct LstmWaveArgs {
   const float* bsum[16];
 };
 
+// Work units.  A unit is (chunk k of T cell steps, layer, tile); unit index u = (k V + layer n_tiles + tile) with
+// V = n_layers n_tiles, and workgroup p of the (resident) grid runs units p, p + P, p + 2 P, ... in that order.
+//   * T >= L (one chunk): the units are the (tile, layer) pairs, a workgroup walks layers l0, l0 + per, ... of its tile --
+//     used while V <= CUs, and as the fallback form.
+//   * V > CUs: T = 16.  The V "virtual workgroups" then share the CUs in time: every unit hands the recurrent state
+//     (h, c of its 16 samples) to the unit that continues the (tile, layer) through a state block in global memory,
+//     published with the same write-through + flag protocol as the rows; all (tile, layer) pairs advance at
+//     CUs / V of full speed instead of the last layers running alone on a quarter of the chip.
+// A unit depends on units of smaller index only ((k - 1, layer, tile) for the state, (k, layer - 1, tile) for the
+// rows, polled as they are produced), and a workgroup runs its units in index order: the unfinished unit of smallest
+// index is always running with its dependencies done, so the grid cannot deadlock (every spin is bounded anyway).
 template <int D>
 __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, LstmWaveArgs wa, int n_layers, int n_tiles,
-                                                      int per, int B, int L, int* __restrict__ prog) {
-  // The grid is `per` layers x n_tiles workgroups, all resident.  Workgroup (layer l0, tile) runs layer l0 and then, on
-  // the same CU, layers l0 + per, l0 + 2 per, ... of its tile: when it finishes a layer the layer below its next one
-  // (started per - 1 layers after its own) is ~7 (per - 1) steps from its end, so the next assignment runs without
-  // waiting -- n_layers x n_tiles workgroup-runs go through the CUs as a continuous stream instead of
-  // ceil(n_layers / per) launches that each drain.  Every poll is on a workgroup that is resident: no deadlock.
+                                                      int T, int B, int L, int* __restrict__ prog,
+                                                      float* __restrict__ state) {
   // Eight waves, two per SIMD, in two roles (the cell step of k_lstm_mfma split in two):
   //   waves 0-3 (recurrent): acc = gx_t image; acc += W_hh h_{t-1}^T (W_hh fragments in VGPRs); lane-local cell
   //                          update; h_t -> LDS.  Only this is on the recurrence's critical path.
@@ -437,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   constexpr int NF4 = 16 * NT;       // float4 slots of a 16-row tile
   constexpr int NSL = (NF4 + 255) / 256;  // slots per thread (of the 256 input-role threads)
   constexpr int CHP = 2;             // cell steps between two publications of a layer's progress
+  constexpr int SST = 16 * D + 4 * NTW * 64;  // floats of a (tile, layer) state block: h rows, then c per recurrent lane
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) float lds[];
   float4* gxi = reinterpret_cast<float4*>(lds);       // [2][NT tiles][64 lanes] gate pre-activations, accumulator layout
@@ -449,43 +457,63 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   // recurrent wave w (wave w + 4) takes the mirrored share, so that every SIMD carries 9 tiles per step
   const int wave = recur ? wave8 : 7 - wave8;
   const int tg = threadIdx.x & 255;
-  const int layer0 = blockIdx.x / n_tiles, tile = blockIdx.x - layer0 * n_tiles;  // (uniform)
   const int j = lane & 15, q = lane >> 4;
   const int t0 = wave * (NT / 4) + min(wave, NT % 4);
   const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
-  for (int layer = layer0; layer < n_layers; layer += per) {
-  const float* wsrc = recur ? wa.whh[layer] : wa.wih[layer];
-  const float* bsum = wa.bsum[layer];
-  int* my_prog = prog + layer * n_tiles + tile;
-  const int* up_prog = layer > 0 ? prog + (layer - 1) * n_tiles + tile : nullptr;
+  const int V = n_layers * n_tiles;
+  const int K = (L + T - 1) / T;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(x, 0, (int)((size_t)B * L * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst =
+      __builtin_amdgcn_make_buffer_rsrc(state, 0, state ? (int)((size_t)V * SST * 4) : 0, 0x00020000);
 
   // this role's weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]); row order inside a
-  // 16-row tile is (unit, gate) = (i >> 2, i & 3), see k_lstm_mfma
+  // 16-row tile is (unit, gate) = (i >> 2, i & 3), see k_lstm_mfma.  Loaded at the start of every unit (as loop-carried
+  // registers, prefetched at the end of the previous unit, they cost the kernel its register budget: 1 KB of scratch).
   float wf[NTW][NT];
   f32x4 bias[NTW];
+  auto load_weights = [&](int layer) {
+    const float* wsrc = recur ? wa.whh[layer] : wa.wih[layer];
+    const float* bsum = wa.bsum[layer];
 #pragma unroll
-  for (int tt = 0; tt < NTW; ++tt) {
-    const int T = min(t0 + tt, NT - 1);
-    const bool on = tt < ntw;
-    const size_t row = (size_t)((j & 3) * D + 4 * T + (j >> 2)) * D;
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int Tt = min(t0 + tt, NT - 1);
+      const bool on = tt < ntw;
+      const size_t row = (size_t)((j & 3) * D + 4 * Tt + (j >> 2)) * D;
 #pragma unroll
-    for (int s = 0; s < NT; ++s) wf[tt][s] = on ? wsrc[row + 4 * s + q] : 0.f;
+      for (int s = 0; s < NT; ++s) wf[tt][s] = on ? wsrc[row + 4 * s + q] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
-  }
-  for (int i = threadIdx.x; i < 2 * 16 * HS; i += 512) hbuf[i] = 0.f;
+      for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * Tt + q] : 0.f;
+    }
+  };
+
+  for (int u = blockIdx.x; u < K * V; u += gridDim.x) {
+  const int kc = u / V, rem = u - kc * V;
+  const int layer = rem / n_tiles, tile = rem - layer * n_tiles;  // (uniform)
+  const int tb = kc * T, te = min(L, tb + T);                     // this unit's cell steps [tb, te); tb is even
+  int* my_prog = prog + layer * n_tiles + tile;
+  const int* up_prog = layer > 0 ? prog + (layer - 1) * n_tiles + tile : nullptr;
+  const unsigned st_base = (unsigned)((layer * n_tiles + tile) * SST * 4);  // byte offset of the state block
+  load_weights(layer);
+  if (kc == 0)
+    for (int i = threadIdx.x; i < 2 * 16 * HS; i += 512) hbuf[i] = 0.f;
 
   if (recur) {
     // ------------------------------------------------------------------ recurrent role
     float c[NTW];
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) c[tt] = 0.f;
-    __syncthreads();  // A
+    __syncthreads();  // A (the input role has seen this (tile, layer)'s previous chunk published)
+    if (kc > 0) {
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        c[tt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rst, st_base + (unsigned)((16 * D + (wave * NTW + tt) * 64 + lane) * 4), 0, 16));  // sc1
+    }
     __syncthreads();  // B
-    __syncthreads();  // C: gx_0 is in image 0
-    for (int t = 0; t < L; ++t) {
+    __syncthreads();  // C: gx_tb is in image 0, h_{tb-1} in h image 0
+    for (int t = tb; t < te; ++t) {
       const int cur = t & 1;
-      if (t > 0) __syncthreads();  // h_{t-1} (h image cur) and gx_t (image cur) are complete
+      if (t > tb) __syncthreads();  // h_{t-1} (h image cur) and gx_t (image cur) are complete
       f32x4 acc[NTW];
 #pragma unroll
       for (int tt = 0; tt < NTW; ++tt) {
@@ -509,17 +537,24 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
           hbuf[((cur ^ 1) * 16 + j) * HS + 4 * (t0 + tt) + q] = go2 * tanh_fast(c[tt]);
         }
     }
-    __syncthreads();  // h_{L-1} complete
+    if (te < L) {  // the cell state goes to the unit that continues this (tile, layer)
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c[tt]), rst,
+                                              st_base + (unsigned)((16 * D + (wave * NTW + tt) * 64 + lane) * 4), 0, 16);  // sc1
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();  // h_{te-1} complete (and this role's state stores have left)
     __syncthreads();  // (the input role's last stores have left)
-    continue;         // next assignment (both roles pass the same L + 4 barriers per layer)
+    continue;         // next unit (both roles pass the same te - tb + 4 barriers per unit)
   }
 
   // -------------------------------------------------------------------- input role
   // this thread's float4 slots of the tile's rows: slot f -> row f / NT, columns 4 (f % NT) .. +3; byte offsets
   // into the (B, L, d) buffer for the raw-buffer (sc1) loads and stores
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(x, 0, (int)((size_t)B * L * D * 4), 0x00020000);
   const int b0 = tile * 16;
   unsigned go[NSL];  // byte offset of the slot at t = 0 (sample clamped; stores masked by `ok`)
+  unsigned so[NSL];  // byte offset of the slot's h values in the state block
   int lo[NSL];
   bool has[NSL], ok[NSL];
 #pragma unroll
@@ -529,6 +564,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
     const int r = min(f, NF4 - 1) / NT, c4 = min(f, NF4 - 1) - r * NT;
     ok[k] = has[k] && b0 + r < B;
     go[k] = (unsigned)(((size_t)min(b0 + r, B - 1) * L * D + 4 * c4) * 4);
+    so[k] = st_base + (unsigned)((r * D + 4 * c4) * 4);
     lo[k] = r * HS + 4 * c4;
   }
   auto gload = [&](int t, float4 (&dst)[NSL]) {
@@ -556,21 +592,24 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
       if (ok[k]) {
         const float2* h2 = reinterpret_cast<const float2*>(hbuf + par * 16 * HS + lo[k]);
         const float2* x2 = reinterpret_cast<const float2*>(xbuf + xs * 16 * HS + lo[k]);
-        const float2 a = h2[0], b = h2[1], u = x2[0], v = x2[1];
-        const f32x4 o = f32x4{u.x + a.x, u.y + a.y, v.x + b.x, v.y + b.y};
+        const float2 a = h2[0], b = h2[1], u2 = x2[0], v = x2[1];
+        const f32x4 o = f32x4{u2.x + a.x, u2.y + a.y, v.x + b.x, v.y + b.y};
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs, go[k] + (unsigned)t * (D * 4), 0, 16);  // sc1
       }
   };
-  // wave 4 waits until the layer below has published `need` cell steps (the other waves meet it at the step barrier)
-  int known = layer > 0 ? 0 : L;
-  auto await_rows = [&](int need) {
+  // wave 4 waits until `word` has reached `need` (the other waves meet it at the next workgroup barrier)
+  auto await_word = [&](const int* word, int& known, int need) {
     if (wave8 == 4 && known < need) {
-      for (int spin = 0; spin < (1 << 24); ++spin) {
-        known = __hip_atomic_load(up_prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int spin = 0; spin < (1 << 22); ++spin) {
+        known = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (known >= need) break;
         __builtin_amdgcn_s_sleep(4);
       }
     }
+  };
+  int known = layer > 0 ? 0 : L;  // cell steps the layer below is known to have published
+  auto await_rows = [&](int need) {
+    if (layer > 0) await_word(up_prog, known, need);
   };
   // gx image `img` <- b + W_ih x^T for this wave's tiles, x fragments from ring slot `par`
   auto input_part = [&](int par, int img) {
@@ -593,57 +632,82 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
 #pragma unroll
   for (int k = 0; k < NSL; ++k) nld += (256 * k + 64 * (wave8 & 3) < NF4) ? 1 : 0;
   float4 xn[NSL];
-  await_rows(min(3, L));
-  __syncthreads();  // A
-  gload(0, xn);
-  xput(0, xn);
-  if (L > 1) {
-    gload(1, xn);
-    xput(1, xn);
+  if (kc > 0) {  // the unit that ran steps < tb of this (tile, layer) has published them, its state included
+    int mine = 0;
+    await_word(my_prog, mine, tb);
   }
-  if (L > 2) gload(2, xn);
+  await_rows(min(tb + 3, te));
+  __syncthreads();  // A
+  if (kc > 0) {  // h_{tb-1} -> h image 0 (tb is even)
+#pragma unroll
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rst, so[k], 0, 16));  // sc1
+        float2* d2 = reinterpret_cast<float2*>(hbuf + lo[k]);
+        d2[0] = float2{v[0], v[1]};
+        d2[1] = float2{v[2], v[3]};
+      }
+  }
+  {  // the first three rows' loads in flight together (one memory latency, not three)
+    float4 xa[NSL], xb[NSL];
+    gload(tb, xa);
+    if (tb + 1 < te) gload(tb + 1, xb);
+    if (tb + 2 < te) gload(tb + 2, xn);
+    xput(0, xa);
+    if (tb + 1 < te) xput(1, xb);
+  }
   __syncthreads();  // B: ring slots 0, 1 written
   input_part(0, 0);
   __syncthreads();  // C
   int s0 = 0, s1 = 1, s2 = 2;  // ring slots of x_t, x_{t+1}, x_{t+2} (= the slot x_{t-1} occupied)
-  for (int t = 0; t < L; ++t) {
+  for (int t = tb; t < te; ++t) {
     const int cur = t & 1;
-    // publication due: rows 0 .. t-2 were stored during earlier iterations; each wave retires its own stores (its
+    // publication due: rows tb .. t-2 were stored during earlier iterations; each wave retires its own stores (its
     // `nld` row loads of step t+2 are younger and may stay in flight), the barrier collects the waves, one lane signs
-    const bool publish = t >= 2 && (t - 1) % CHP == 0;
-    if (t > 0) {
+    const bool publish = t >= tb + 2 && (t - 1) % CHP == 0;
+    if (t > tb) {
       if (publish) {
-        if (t + 2 >= L) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t + 2 >= te) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (nld == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (nld == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      await_rows(min(t + 4, L));
+      await_rows(min(t + 4, te));
       __syncthreads();  // h_{t-1}, gx_t, x_{t+1} (ring slot s1) complete
       if (publish && tg == 0) __hip_atomic_store(my_prog, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out_store(t - 1, cur, s2);  // x_{t-1} + h_{t-1}
     } else {
-      await_rows(min(4, L));
+      await_rows(min(tb + 4, te));
     }
-    if (t + 1 < L) input_part(s1, cur ^ 1);  // gx_{t+1}
+    if (t + 1 < te) input_part(s1, cur ^ 1);  // gx_{t+1}
     // slot s2 held x_{t-1}: its fragments were read two steps ago and this thread just wrote its rows back
-    if (t + 2 < L) xput(s2, xn);
-    if (t + 3 < L) gload(t + 3, xn);
+    if (t + 2 < te) xput(s2, xn);
+    if (t + 3 < te) gload(t + 3, xn);
     const int r = s0;
     s0 = s1, s1 = s2, s2 = r;
   }
-  __syncthreads();  // h_{L-1} complete
-  out_store(L - 1, L & 1, s2);
+  __syncthreads();  // h_{te-1} complete
+  out_store(te - 1, te & 1, s2);
+  if (te < L) {  // h_{te-1} (h image te & 1) -> the state block
+#pragma unroll
+    for (int k = 0; k < NSL; ++k)
+      if (has[k]) {
+        const float2* h2 = reinterpret_cast<const float2*>(hbuf + (te & 1) * 16 * HS + lo[k]);
+        const float2 a = h2[0], b = h2[1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{a.x, a.y, b.x, b.y}), rst, so[k], 0, 16);  // sc1
+      }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tg == 0) __hip_atomic_store(my_prog, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }  // assignments
+  if (tg == 0) __hip_atomic_store(my_prog, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }  // units
 }
 
 constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5 * 16 * (D + 2)) * 4; }
 
-int g_lstm_wave_persist = 1;  // workgroups walk their tile's layers (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
+int g_lstm_wave_persist = 1;  // 1: one launch, workgroups run their units in order (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
 int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
+int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
 int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
 
 bool lstm_wave_selected(int B, int D) {
@@ -652,9 +716,15 @@ bool lstm_wave_selected(int B, int D) {
   return g_lstm_wave == 2 || !lstm_mfma_selected(B, D);
 }
 
+// floats of the state blocks (h rows + cell values per recurrent lane) of the time-chunked form, <= 16 layers per launch
+size_t lstm_wave_state_floats(int B, int D, int NL) {
+  const int nl = NL < 16 ? NL : 16;
+  return (size_t)nl * cdiv(B, 16) * (16 * D + 4 * ((D / 4 + 3) / 4) * 64);
+}
+
 template <int D>
 static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const float* const* whh, const float* const* bsum,
-                                     int NL, int B, int L, int* prog, hipStream_t s) {
+                                     int NL, int B, int L, int* prog, float* state, hipStream_t s) {
   constexpr size_t lds = lstm_wave_lds(D);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_wave<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -665,18 +735,36 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
   if (g_lstm_wave_per > 0 && g_lstm_wave_per < per) per = g_lstm_wave_per;
   if (per > 16) per = 16;
   if (per < 1) return hipErrorInvalidValue;
-  // up to 16 layers per launch (the argument block); within a launch the workgroups walk their tile's layers
+  const int Lfull = L + (L & 1);  // one chunk (an even step count >= L)
+  // up to 16 layers per launch (the argument block)
   for (int l0 = 0; l0 < NL; l0 += 16) {
     const int nl = NL - l0 < 16 ? NL - l0 : 16;
-    const int pl = g_lstm_wave_persist ? (per < nl ? per : nl) : per;
+    // Time-shared units where walking whole layers would leave CUs idle in the last pass (10 layers on 8 layers' worth
+    // of workgroups: the last two run alone).  nl / per passes of the (tile, layer) pairs per chunk: with
+    // K = per / gcd(nl, per) chunks the K nl / per rounds come out whole (B = 512: 10 layers, 8 in flight -> 4 chunks
+    // of 64 steps in 5 rounds instead of 2 passes of 251 steps); a unit costs ~ 10-20 us of hand-over, so K <= 8.
+    int Kc = 1;
+    {
+      int a = nl, b2 = per;
+      while (b2) { const int t = a % b2; a = b2, b2 = t; }
+      Kc = per / a;
+      if (Kc > 8) Kc = 8;
+    }
+    int Tc = g_lstm_wave_chunk >= 2 ? (g_lstm_wave_chunk & ~1) : (cdiv(L, Kc) + 1) & ~1;
+    const bool chunked = g_lstm_wave_persist && g_lstm_wave_chunk != 1 && state != nullptr && nl > per && Tc < L &&
+                         (Kc > 1 || g_lstm_wave_chunk >= 2);
     for (int l1 = 0; l1 < nl; l1 += (g_lstm_wave_persist ? nl : per)) {
       const int n1 = g_lstm_wave_persist ? nl : (nl - l1 < per ? nl - l1 : per);
       LstmWaveArgs wa{};
       for (int i = 0; i < n1; ++i) wa.wih[i] = wih[l0 + l1 + i], wa.whh[i] = whh[l0 + l1 + i], wa.bsum[i] = bsum[l0 + l1 + i];
       hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)n1 * n_tiles, s);
       if (e != hipSuccess) return e;
-      const int first = pl < n1 ? pl : n1;
-      hipLaunchKernelGGL((k_lstm_wave<D>), dim3(first * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, first, B, L, prog);
+      // chunked: the V = n1 n_tiles (tile, layer) pairs share min(V, per n_tiles) resident workgroups in units of T
+      // steps; else every workgroup walks layers l0', l0' + per, ... of its tile
+      const int T = chunked ? Tc : Lfull;
+      const int first = per < n1 ? per : n1;
+      hipLaunchKernelGGL((k_lstm_wave<D>), dim3(first * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, T, B, L, prog,
+                         chunked ? state : nullptr);
       e = hipGetLastError();
       if (e != hipSuccess) return e;
     }
@@ -685,12 +773,12 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
 }
 
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
-                            int B, int L, int D, int* prog, hipStream_t s) {
+                            int B, int L, int D, int* prog, float* state, hipStream_t s) {
   if (B <= 0 || NL <= 0) return hipSuccess;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (size_t)B * L * D * 4 >= (1ull << 31)) return hipErrorInvalidValue;
   switch (D) {
 #define X(d) \
-  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, s);
+  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, s);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;

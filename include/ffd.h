@@ -318,9 +318,12 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "lstm_wave" = 1 | 0 | 2                    LSTM below that batch: all layers as a wavefront of (16-sample tile, layer)
  *                                              workgroups (k_lstm_wave), or the per-layer kernels (0); 2 = at every
  *                                              batch (test suite);
- *   "lstm_wave_persist" = 1 | 0                its workgroups walk their tile's layers l0, l0 + per, ... in one launch, or
- *                                              one launch per group of `per` layers; "lstm_wave_per" = n: at most n
- *                                              layers in flight (0 = as many as the CUs hold; tests);
+ *   "lstm_wave_persist" = 1 | 0                one launch whose resident workgroups run (chunk, layer, tile) units in
+ *                                              index order, or one launch per group of `per` layers;
+ *                                              "lstm_wave_per" = n: at most n layers in flight (0 = as many as the CUs
+ *                                              hold; tests); "lstm_wave_chunk" = 0 | 1 | even n: cell steps per
+ *                                              unit where the (tile, layer) pairs outnumber the CUs (0: chosen so that
+ *                                              the rounds come out whole, 1: layers walked whole, n: forced);
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;

@@ -1158,8 +1158,8 @@ def test_lstm_wavefront_golden(ffd, golden, name):
 @pytest.mark.gpu
 def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
     """k_lstm_wave over batch sizes that leave a ragged last tile, one tile, and more tiles than a launch holds with
-    all ten layers (B = 512: 32 tiles -> layers in groups of 8 + 2; B = 1100: 69 tiles -> groups of 3): every sample
-    equals its evaluation in a small batch, a slice equals the oracle."""
+    all ten layers (B = 512: 32 tiles x 10 layers on 256 workgroups; B = 1100: 69 tiles -> 3 layers in flight): every
+    sample equals its evaluation in a small batch, a slice equals the oracle."""
     c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
     m, _ = make_model(ffd, c)
     sd = make_sd(c)
@@ -1179,9 +1179,13 @@ def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
             # for any number of layers in flight
             from fastfourierdiffusion_amd import _native as N
             lib = N.lib()
-            for per, persist in ((0, 0), (1, 1), (2, 1), (3, 1), (3, 0)):
+            # ... and where the (tile, layer) pairs outnumber the workgroups, for any chunk length of the time-shared
+            # form (units of `chunk` cell steps, state handed over through memory; 1 = layers walked whole, 0 = the default choice)
+            for per, persist, chunk in ((0, 0, 16), (1, 1, 16), (2, 1, 2), (3, 1, 64), (3, 0, 16), (0, 1, 1), (0, 1, 30),
+                                        (2, 1, 1), (3, 1, 0), (4, 1, 0)):
                 assert lib.ffd_tune(b"lstm_wave_per", per) == 0 and lib.ffd_tune(b"lstm_wave_persist", persist) == 0
-                assert torch.equal(m(batch_of(x.cuda(), 0.45)).cpu(), out), (B, per, persist)
+                assert lib.ffd_tune(b"lstm_wave_chunk", chunk) == 0
+                assert torch.equal(m(batch_of(x.cuda(), 0.45)).cpu(), out), (B, per, persist, chunk)
             assert lib.ffd_tune(b"reset", 0) == 0
 
 
