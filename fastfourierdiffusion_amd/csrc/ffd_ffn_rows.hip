@@ -330,11 +330,6 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   auto slot_src = [&](int wslot) -> const float* {  // packed slot `wslot` of a tile's stream
     return OP ? (wslot == 0 ? ringp : ring_s + (size_t)(wslot - 1) * C::SLOT_FLOATS) : ring_s + (size_t)wslot * C::SLOT_FLOATS;
   };
-  auto issue_ring = [&](int wslot, int rslot) {  // packed slot `wslot` of the layer -> ring slot `rslot`
-    const float* src = slot_src(wslot) + lane * 4;
-    const unsigned dst = ring_base + (unsigned)rslot * (C::SLOT_FLOATS * 4);
-    for (int g = wave; g < C::SLOT_G; g += NW) dma_piece(src + g * 256, dst + g * 1024);
-  };
 
   float4 xv[CTA][4], xrem[NRA];  // X rows (B operands of GEMM1 and the residual)
   f32x16 yacc[CTA];
@@ -380,19 +375,33 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
     for (int g = 0; g < NGA; ++g) yrem[g] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // ---- prologue: LN parameters, first AHEAD slots; the first tile's rows are requested under the ring fill ----
+  // ---- prologue: LN parameters; the first slot and the first tile's rows are waited for, the second slot's pieces
+  //      stay in flight (certified by the first slot barrier: mid-slot in the out-projection slot / the chunk slot) ----
+  static_assert(C::AHEAD == 2 || !OP, "prologue of the fused form");
   for (int i = threadIdx.x; i < (OP ? 6 : 3) * D; i += 64 * NW)
     lnp[i] = i < D ? b2[i] : i < 2 * D ? gam[i - D] : i < 3 * D ? bet[i - 2 * D]
            : i < 4 * D ? bo[i - 3 * D] : i < 5 * D ? gam1[i - 4 * D] : bet1[i - 5 * D];
-#pragma unroll
-  for (int j = 0; j < C::AHEAD; ++j)
-    if (j < total) issue_ring(j % NSL, j % NSLOT);
+  {
+    const float* src = slot_src(0) + lane * 4;  // (the out-projection slot has NFP fragment groups, the rest is padding)
+    for (int g = wave; g < (OP ? NFP : C::SLOT_G); g += NW) dma_piece(src + g * 256, ring_base + g * 1024);
+  }
   float4 rin[CTA][4], rinrem[NRA];  // fused form: the layer input rows (LN1's residual)
   load_rows(X, xv, xrem);
   if (OP) load_rows(Rin, rin, rinrem);
   wait_vm<0>();
   retire_rows(xv, xrem);
   if (OP) retire_rows(rin, rinrem);
+#pragma unroll
+  for (int j = 1; j < C::AHEAD; ++j)
+    if (j < total) {  // NPW pieces per wave (a piece index past the slot wraps: fetched twice), like the slots after it
+      const float* src = slot_src(j % NSL) + lane * 4;
+      const unsigned dst = ring_base + (unsigned)(j % NSLOT) * (C::SLOT_FLOATS * 4);
+#pragma unroll
+      for (int i = 0; i < C::NPW; ++i) {
+        const int g0 = wave + i * NW, g = g0 < C::SLOT_G ? g0 : g0 - C::SLOT_G;
+        dma_piece(src + g * 256, dst + g * 1024);
+      }
+    }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the LN parameter writes
   __builtin_amdgcn_s_barrier();
 
@@ -482,6 +491,13 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
               for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(nslot + NFC * 256 + 4 * (2 * t + half_i));
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (K == NPM - 1) {
+          // the next slot (the tile's first chunk slot) is read from here on: my pieces of it have landed (the burst
+          // above, younger, stays in flight); after the first tile the head barrier has certified it already
+          if (dma_on) wait_vm<C::NPW>(); else wait_vm<0>();
+          __builtin_amdgcn_s_barrier();
           __builtin_amdgcn_sched_barrier(0);
         }
       }
