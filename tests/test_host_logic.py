@@ -450,3 +450,26 @@ def test_isa_lint_clean_on_every_kernel_source():
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fastfourierdiffusion_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "lint", "-j4"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # The hot kernels' register budgets, from the metadata of the same ISA files: the row-owning FFN keeps its 50-group
+    # fragment stream unrolled (past LLVM's default full-unroll budget it stays a loop, indexes the fragment array at run
+    # time and goes to ~1 KB of scratch: 6-10 ms launches) and the instances the ECG and config-5 benches launch
+    # (12 and 8 waves, two-chunk slots) hold no scratch inside their slot loops: at most the 88 B of the multi-tile
+    # fused form's tile boundaries; the LSTM wavefront at d_model 72 holds none.
+    import re
+
+    def kernels(path):
+        txt = open(path).read()
+        names = re.findall(r"^\s+\.name:\s+(\S+)", txt, re.M)
+        priv = re.findall(r"^\s+\.private_segment_fixed_size:\s+(\d+)", txt, re.M)
+        assert len(names) == len(priv)
+        return dict(zip(names, map(int, priv)))
+
+    rows = {k: v for k, v in kernels(os.path.join(csrc, ".isa", "ffd_ffn_rows.s")).items() if "k_ffn_rows" in k}
+    assert len(rows) >= 10
+    for name, scratch in rows.items():
+        assert scratch <= 128, (name, scratch)
+        if "ELb1EEEv" in name:  # one tile per workgroup (the ECG B = 512 launch): nothing spilled at all
+            assert scratch == 0, (name, scratch)
+    wave = {k: v for k, v in kernels(os.path.join(csrc, ".isa", "ffd_lstm.s")).items() if "k_lstm_waveILi72E" in k}
+    assert wave and all(v == 0 for v in wave.values()), wave
+
