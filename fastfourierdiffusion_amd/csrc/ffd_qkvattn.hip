@@ -26,6 +26,18 @@ namespace ffd {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// acc += p.lo * v  /  acc += p.hi * v  with the scalar broadcast done by the instruction's operand select (no v_mov to
+// build a {p, p} pair: 16 of the ~93 vector instructions of a 32x32 score tile): p is a pair of adjacent accumulator
+// registers of the S^T tile.  The same FMAs, bit for bit.
+__device__ __forceinline__ f32x2 pk_fma_lo(f32x2 p, f32x2 v, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(p), "v"(v));
+  return acc;
+}
+__device__ __forceinline__ f32x2 pk_fma_hi(f32x2 p, f32x2 v, f32x2 acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(p), "v"(v));
+  return acc;
+}
+
 // ---- weight pack ---------------------------------------------------------------------------------
 // awp[h][ct][step4][lane][4]: the B operand of k-step (4*step4 + i) for lane (n = lane & 15, q = lane >> 4):
 //   full 16-chunks j < D/16 : k = 16 j + 4 q + i          (step4 = j)
@@ -426,9 +438,9 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
+          const f32x2 pp = f32x2{sc[g][r & ~1], sc[g][(r & ~1) + 1]};  // (adjacent registers of the accumulator)
 #pragma unroll
-          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
+          for (int e = 0; e < HP; ++e) acc[g][e] = (r & 1) ? pk_fma_hi(pp, vv[e], acc[g][e]) : pk_fma_lo(pp, vv[e], acc[g][e]);
         }
         if (r + PF < 16) {
           load_v(r + PF, kbase, vb[r % PF]);
@@ -807,9 +819,9 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         for (int e = 0; e < 4; ++e) vv[e] = vb[r % PF][e];
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-          const f32x2 p2 = f32x2{sc[g][r], sc[g][r]};
+          const f32x2 pp = f32x2{sc[g][r & ~1], sc[g][(r & ~1) + 1]};  // (adjacent registers of the accumulator)
 #pragma unroll
-          for (int e = 0; e < HP; ++e) acc[g][e] = __builtin_elementwise_fma(p2, vv[e], acc[g][e]);
+          for (int e = 0; e < HP; ++e) acc[g][e] = (r & 1) ? pk_fma_hi(pp, vv[e], acc[g][e]) : pk_fma_lo(pp, vv[e], acc[g][e]);
         }
         if (r + PF < 16) {
           load_v(r + PF, kbase, vb[r % PF]);
