@@ -1334,16 +1334,17 @@ def test_ffn_rows_tile_to_wave_assignment_never_shows(ffd):
     assert rel_err(old.cpu(), ref.cpu()) < 2e-6
 
 
-def test_rows_sliced_form_agrees_with_the_other_forms(ffd):
+@pytest.mark.parametrize("name,batches", [("ecg", (24, 96, 130)), ("syn", (30, 48))])
+def test_rows_sliced_form_agrees_with_the_other_forms(ffd, name, batches):
     """Mid-size batches run the fused out-proj + FFN kernel over tiles x slices of the hidden dimension (a unit per CU)
     and add the slices' partial rows in order in a reduce / LN2 launch: every (waves, slices) choice agrees with the
     forms it replaces to rounding, is deterministic, and a sample's result does not depend on the batch around it."""
     from fastfourierdiffusion_amd import _native as N
 
-    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
     m, _ = make_model(ffd, c)
     lib = N.lib()
-    for B in (24, 96, 130):
+    for B in batches:
         x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4242 + B))).cuda()
         assert lib.ffd_tune(b"rows_slices", -1) == 0
         ref = m(batch_of(x, 0.4))
