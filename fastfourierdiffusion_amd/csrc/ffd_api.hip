@@ -190,7 +190,7 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
-    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1792,
+    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 8192,
     g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1;
     return FFD_OK;
   }
@@ -677,7 +677,8 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
     TIMED(FFD_K_EMBED, launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb,
                                     temb_stride, ctx->h0, B, L, C, d, s));
     if (lstm_wave_selected(B, d) && m.num_layers <= 64) {  // mid-size batches: the layers as a wavefront (ffd_lstm.hip)
-      const size_t need = (size_t)16 * cdiv(B, 16);
+      const int Bw = B < lstm_wave_max_batch() ? B : lstm_wave_max_batch();  // samples per launch
+      const size_t need = (size_t)16 * cdiv(Bw, 16);
       if (need > ctx->lstm_prog_ints) {
         float* pbuf = reinterpret_cast<float*>(ctx->lstm_prog);
         if (int rc = dev_regrow(ctx, &pbuf, need)) return rc;
@@ -685,12 +686,16 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       }
       const float *wih[64], *whh[64], *bs[64];
       for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].wih, whh[i] = ctx->lstm[i].whh, bs[i] = ctx->lstm[i].bsum;
-      const size_t need_st = lstm_wave_state_floats(B, d, m.num_layers);
+      const size_t need_st = lstm_wave_state_floats(Bw, d, m.num_layers);
       if (need_st > ctx->lstm_state_floats) {
         if (int rc = dev_regrow(ctx, &ctx->lstm_state, need_st)) return rc;
         ctx->lstm_state_floats = need_st;
       }
-      TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0, wih, whh, bs, m.num_layers, B, L, d, ctx->lstm_prog, ctx->lstm_state, s));
+      for (int b0 = 0; b0 < B; b0 += Bw) {  // (samples are independent: sub-batches of a tile per CU, one after the other)
+        const int nb = B - b0 < Bw ? B - b0 : Bw;
+        TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0 + (size_t)b0 * L * d, wih, whh, bs, m.num_layers, nb, L, d,
+                                               ctx->lstm_prog, ctx->lstm_state, s));
+      }
     } else
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];

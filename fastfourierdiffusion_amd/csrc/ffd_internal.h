@@ -212,6 +212,7 @@ hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const 
 // batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
 // prog: >= 16 * ceil(B / 16) ints of device scratch (progress words, cleared by the launcher)
 bool lstm_wave_selected(int B, int D);
+int lstm_wave_max_batch();  // samples one k_lstm_wave launch takes (a 16-sample tile per CU); larger batches go in sub-batches
 extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk;
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
                             int B, int L, int D, int* prog, float* state, hipStream_t s);

@@ -391,8 +391,13 @@ constexpr size_t lstm_mfma_lds(int D, int GRP) {
   return (size_t)(4 * NG * NTW * 64) * 16 + (size_t)GRP * 5 * 16 * (D + 2) * 4 + 16;
 }
 
-// batch from which the batch-tiled kernel is faster than one sample per workgroup (measured crossover)
-int g_lstm_mfma_min_batch = 1792;
+// Batch from which the batch-tiled kernel runs.  Where it applies (a 16-sample tile per CU, B <= 4096) k_lstm_wave is
+// the faster form at every batch (samples/s at 1000 steps, wave | mfma: B = 1536 387 | 180, 2048 513 | 238,
+// 3072 393 | 355, 4096 519 | 470) -- the crossover of round 2 (1792) was measured against the
+// one-sample-per-workgroup kernel the wavefront has replaced -- and between 4096 and 8192 samples the wavefront over
+// sub-batches of <= 4096 beats it too (B = 6144: 4096 + 2048 in 7.9 + 4.0 ms against 15.8).  From 8192 on the two
+// forms tie (0.70 of the matrix peak each) and the batch-tiled kernel keeps the path.
+int g_lstm_mfma_min_batch = 8192;
 int g_lstm_mfma_s = 0;  // 16-sample groups per workgroup: 0 = by batch, 1, 2
 
 bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
@@ -710,9 +715,10 @@ int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
 int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
 int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
 
+// (batches past a 16-sample tile per CU go through the launcher in sub-batches of 16 CUs samples)
+int lstm_wave_max_batch() { return 16 * num_cus(); }
 bool lstm_wave_selected(int B, int D) {
   if (g_lstm_wave == 0 || D % 4 != 0 || D < 16) return false;
-  if (cdiv(B, 16) > num_cus()) return false;  // a 16-sample tile per CU and layer
   return g_lstm_wave == 2 || !lstm_mfma_selected(B, D);
 }
 

@@ -447,9 +447,10 @@ def test_lstm_full_batch_properties(ffd):
 
 
 def test_lstm_production_batch_selection(ffd):
-    """BASELINE configs[3] shape at B = 2048: the batch the production selection hands to k_lstm_mfma (B >= 1792; no
-    ffd_tune here).  Sample independence against small-batch evaluations (k_lstm_layer) for three picks, a two-sample
-    slice against the oracle, and the kernel class bench.py would report."""
+    """BASELINE configs[3] shape at the batches the production selection (no ffd_tune here) hands to its two large-batch
+    forms: B = 2048 and B = 4352 to the layer wavefront (k_lstm_wave: a 16-sample tile per CU, larger batches in
+    sub-batches of 4096), B = 8192 (only its kernel class is checked here) to the batch-tiled recurrence (k_lstm_mfma).  Sample independence against small-batch evaluations for three picks, a
+    two-sample slice against the oracle, and the kernel class bench.py would report."""
     import ctypes as C
 
     from fastfourierdiffusion_amd import _native as N
@@ -457,20 +458,21 @@ def test_lstm_production_batch_selection(ffd):
     c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
     m, _ = make_model(ffd, c)
     sd = make_sd(c)
-    B = 2048
-    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444)))
-    out = m(batch_of(x.cuda(), 0.45)).cpu()
-    assert torch.isfinite(out).all()
-    ctx = m._ctx()
-    fl, by = C.c_double(), C.c_double()
-    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, B, 0, C.byref(fl), C.byref(by)) == b"k_lstm_mfma"
-    assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_wave"
-    for b in (0, 1023, 2047):
-        one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
-        assert rel_err(out[b:b + 1], one) < 2e-6, b
-    t = torch.full((2,), 0.45, dtype=torch.float32)
-    ref = O.lstm_score_forward(x[1500:1502], t, sd, c["NL"])
-    assert rel_err(out[1500:1502], ref) < TOL_SCORE
+    for B, kname in ((2048, b"k_lstm_wave"), (4352, b"k_lstm_wave")):
+        x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444 + B)))
+        out = m(batch_of(x.cuda(), 0.45)).cpu()
+        assert torch.isfinite(out).all()
+        ctx = m._ctx()
+        fl, by = C.c_double(), C.c_double()
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, B, 0, C.byref(fl), C.byref(by)) == kname
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_wave"
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 8192, 0, C.byref(fl), C.byref(by)) == b"k_lstm_mfma"
+        for b in (0, B // 2 - 1, B - 1):
+            one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
+            assert rel_err(out[b:b + 1], one) < 2e-6, (B, b)
+        t = torch.full((2,), 0.45, dtype=torch.float32)
+        ref = O.lstm_score_forward(x[1500:1502], t, sd, c["NL"])
+        assert rel_err(out[1500:1502], ref) < TOL_SCORE, B
 
 
 @pytest.mark.parametrize("name", ["ecg", "nasa_lstm"])
@@ -1191,7 +1193,7 @@ def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
 
 @pytest.fixture
 def lstm_mfma(ffd):
-    """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 1792 in production) on small batches."""
+    """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 8192 in production) on small batches."""
     from fastfourierdiffusion_amd import _native as N
 
     lib = N.lib()
@@ -1200,7 +1202,7 @@ def lstm_mfma(ffd):
         assert lib.ffd_tune(b"lstm_mfma_min_batch", 1) == 0 and lib.ffd_tune(b"lstm_mfma_s", s) == 0
 
     yield force
-    assert lib.ffd_tune(b"lstm_mfma_min_batch", 1792) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
+    assert lib.ffd_tune(b"lstm_mfma_min_batch", 8192) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
 
 
 @pytest.mark.parametrize("s_tiles", [1, 2])
@@ -1232,7 +1234,7 @@ def test_lstm_mfma_ragged_batch_and_independence(ffd, lstm_mfma, s_tiles):
     sd = make_sd(c)
     B = 37
     x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444)))
-    base = m(batch_of(x.cuda(), 0.45)).cpu()  # k_lstm_layer (B < 1792)
+    base = m(batch_of(x.cuda(), 0.45)).cpu()  # the small-batch form
     noise = list(synthetic.noise_stream((B, c["L"], c["C"]), 7, 4445))
     s0 = DiffusionSampler(m, B)
     s0.inject_noise(iter(noise))
