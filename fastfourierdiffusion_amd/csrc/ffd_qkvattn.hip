@@ -580,6 +580,13 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     float xr[MAXT][REM > 0 ? REM : 1];
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) load_x(min(wave + u * NW, TT - 1), xa[u], xr[u]);
+    // ... and, for the four features on the 4x4x1 form (below), this lane's token row of the wave's 64-token group
+    float4 xq[REMF ? D / 4 : 1];
+    if constexpr (REMF) {
+      const float* xp = xb + (size_t)min(64 * wave + lane, L - 1) * D;
+#pragma unroll
+      for (int c = 0; c < D / 4; ++c) xq[c] = *reinterpret_cast<const float4*>(xp + 4 * c);
+    }
     {
       const float4* Wq = reinterpret_cast<const float4*>(awp) + (size_t)hg * NCT * S4 * 64;
       for (int i = threadIdx.x; i < NCT * S4 * 64; i += 64 * NW) wl[i] = Wq[i];
@@ -657,11 +664,6 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       // four tokens.  72 k-steps, k ascending (the 16x16x4 tiles sum k in another order: rounding-level, per feature).
       const int g = wave;
       if (64 * g < Lp) {
-        const int tok = min(64 * g + lane, L - 1);
-        const float* xp = xb + (size_t)tok * D;
-        float4 xq[D / 4];
-#pragma unroll
-        for (int c = 0; c < D / 4; ++c) xq[c] = *reinterpret_cast<const float4*>(xp + 4 * c);
         const int f = lane & 3;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
