@@ -618,6 +618,7 @@ def main() -> None:
                 measure_other(device, "syn512", 8192, 3, 1, True),
                 measure_other(device, "nasa_lstm", 8192, 20, 2, False),
                 measure_other(device, "nasa_lstm", 512, 20, 5, False),
+                measure_other(device, "nasa_lstm", 2048, 20, 3, False),  # the wavefront with every CU busy
             ]
             out["api_e2e"] = [api_e2e(device, B, "philox"), api_e2e(device, B, "torch")]
             out["api_e2e_over_value"] = out["api_e2e"][0]["samples_per_s"] / value
