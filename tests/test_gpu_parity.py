@@ -1191,6 +1191,33 @@ def test_lstm_wavefront_ragged_batches_and_layer_groups(ffd):
             assert lib.ffd_tune(b"reset", 0) == 0
 
 
+def test_lstm_wavefront_more_layers_than_a_launch_holds(ffd):
+    """k_lstm_wave takes up to 16 layers per launch (its argument block): a 19-layer model runs as 16 + 3, the second
+    launch on the rows the first one left, time-shared or not -- against the oracle and the per-layer kernels."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = dict(next(c for c in cases.MODEL_CASES if c["name"] == "small_lstm"))
+    c["NL"] = 19
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    lib = N.lib()
+    for B in (5, 300):
+        x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 5100 + B)))
+        assert lib.ffd_tune(b"lstm_wave", 2) == 0
+        outs = []
+        for per, chunk in ((0, 0), (3, 4), (5, 1)):
+            assert lib.ffd_tune(b"lstm_wave_per", per) == 0 and lib.ffd_tune(b"lstm_wave_chunk", chunk) == 0
+            outs.append(m(batch_of(x.cuda(), 0.6)).cpu())
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), B
+        assert lib.ffd_tune(b"reset", 0) == 0 and lib.ffd_tune(b"lstm_wave", 0) == 0
+        base = m(batch_of(x.cuda(), 0.6)).cpu()
+        assert lib.ffd_tune(b"reset", 0) == 0
+        assert rel_err(outs[0], base) < 2e-6, B
+        n = min(2, B)
+        ref = O.lstm_score_forward(x[:n], torch.full((n,), 0.6, dtype=torch.float32), sd, c["NL"])
+        assert rel_err(outs[0][:n], ref) < TOL_SCORE, B
+
+
 @pytest.fixture
 def lstm_mfma(ffd):
     """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 8192 in production) on small batches."""
