@@ -5,7 +5,7 @@ f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0][-40:]
+    name = r["Kernel_Name"].split("(")[0][-72:]
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 filt = sys.argv[2:]
 for name, cs in acc.items():
