@@ -422,13 +422,14 @@ struct LstmWaveArgs {
 };
 
 // Work units.  A unit is (chunk k of T cell steps, layer, tile); unit index u = (k V + layer n_tiles + tile) with
-// V = n_layers n_tiles, and workgroup p of the (resident) grid runs units p, p + P, p + 2 P, ... in that order.
-//   * T >= L (one chunk): the units are the (tile, layer) pairs, a workgroup walks layers l0, l0 + per, ... of its tile --
-//     used while V <= CUs, and as the fallback form.
-//   * V > CUs: T = 16.  The V "virtual workgroups" then share the CUs in time: every unit hands the recurrent state
-//     (h, c of its 16 samples) to the unit that continues the (tile, layer) through a state block in global memory,
-//     published with the same write-through + flag protocol as the rows; all (tile, layer) pairs advance at
-//     CUs / V of full speed instead of the last layers running alone on a quarter of the chip.
+// V = n_layers n_tiles, and workgroup p of the (resident) grid of P workgroups runs units p, p + P, p + 2 P, ... in that
+// order.  P is every CU (the V pairs if there are fewer): the grid need not be a multiple of the tile count.
+//   * T >= L (one chunk): the units are the (tile, layer) pairs; V <= CUs: all of them resident, a pure wavefront.
+//   * V > CUs: the pairs go through the CUs in ceil(K V / P) rounds of T = L / K steps.  With K > 1 every unit hands
+//     the recurrent state (h, c of its 16 samples) to the unit that continues the (tile, layer) through a state block
+//     in global memory, published with the same write-through + flag protocol as the rows, and all pairs advance at
+//     P / V of full speed instead of the last pass running on a fraction of the chip; the launcher picks the K with
+//     the least estimated time (a unit costs ~ 15 us of hand-over).
 // A unit depends on units of smaller index only ((k - 1, layer, tile) for the state, (k, layer - 1, tile) for the
 // rows, polled as they are produced), and a workgroup runs its units in index order: the unfinished unit of smallest
 // index is always running with its dependencies done, so the grid cannot deadlock (every spin is bounded anyway).
@@ -737,43 +738,58 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
     if (e != hipSuccess) return e;
   }
   const int n_tiles = cdiv(B, 16);
-  int per = num_cus() / n_tiles;  // layers in flight: every workgroup of a launch is resident
+  if (n_tiles > num_cus()) return hipErrorInvalidValue;  // (the caller hands over sub-batches of a tile per CU)
+  int per = num_cus() / n_tiles;  // whole layers the resident workgroups hold
   if (g_lstm_wave_per > 0 && g_lstm_wave_per < per) per = g_lstm_wave_per;
   if (per > 16) per = 16;
-  if (per < 1) return hipErrorInvalidValue;
   const int Lfull = L + (L & 1);  // one chunk (an even step count >= L)
   // up to 16 layers per launch (the argument block)
   for (int l0 = 0; l0 < NL; l0 += 16) {
     const int nl = NL - l0 < 16 ? NL - l0 : 16;
-    // Time-shared units where walking whole layers would leave CUs idle in the last pass (10 layers on 8 layers' worth
-    // of workgroups: the last two run alone).  nl / per passes of the (tile, layer) pairs per chunk: with
-    // K = per / gcd(nl, per) chunks the K nl / per rounds come out whole (B = 512: 10 layers, 8 in flight -> 4 chunks
-    // of 64 steps in 5 rounds instead of 2 passes of 251 steps); a unit costs ~ 10-20 us of hand-over, so K <= 8.
-    int Kc = 1;
-    {
-      int a = nl, b2 = per;
-      while (b2) { const int t = a % b2; a = b2, b2 = t; }
-      Kc = per / a;
-      if (Kc > 8) Kc = 8;
+    if (!g_lstm_wave_persist) {  // a launch per group of `per` layers, every workgroup one (tile, layer)
+      for (int l1 = 0; l1 < nl; l1 += per) {
+        const int n1 = nl - l1 < per ? nl - l1 : per;
+        LstmWaveArgs wa{};
+        for (int i = 0; i < n1; ++i) wa.wih[i] = wih[l0 + l1 + i], wa.whh[i] = whh[l0 + l1 + i], wa.bsum[i] = bsum[l0 + l1 + i];
+        hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)n1 * n_tiles, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_lstm_wave<D>), dim3(n1 * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, Lfull, B, L, prog,
+                           (float*)nullptr);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+      }
+      continue;
     }
-    int Tc = g_lstm_wave_chunk >= 2 ? (g_lstm_wave_chunk & ~1) : (cdiv(L, Kc) + 1) & ~1;
-    const bool chunked = g_lstm_wave_persist && g_lstm_wave_chunk != 1 && state != nullptr && nl > per && Tc < L &&
-                         (Kc > 1 || g_lstm_wave_chunk >= 2);
-    for (int l1 = 0; l1 < nl; l1 += (g_lstm_wave_persist ? nl : per)) {
-      const int n1 = g_lstm_wave_persist ? nl : (nl - l1 < per ? nl - l1 : per);
-      LstmWaveArgs wa{};
-      for (int i = 0; i < n1; ++i) wa.wih[i] = wih[l0 + l1 + i], wa.whh[i] = whh[l0 + l1 + i], wa.bsum[i] = bsum[l0 + l1 + i];
-      hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)n1 * n_tiles, s);
-      if (e != hipSuccess) return e;
-      // chunked: the V = n1 n_tiles (tile, layer) pairs share min(V, per n_tiles) resident workgroups in units of T
-      // steps; else every workgroup walks layers l0', l0' + per, ... of its tile
-      const int T = chunked ? Tc : Lfull;
-      const int first = per < n1 ? per : n1;
-      hipLaunchKernelGGL((k_lstm_wave<D>), dim3(first * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, T, B, L, prog,
-                         chunked ? state : nullptr);
-      e = hipGetLastError();
-      if (e != hipSuccess) return e;
+    // One launch: P resident workgroups run the K V units (chunk, layer, tile), V = nl n_tiles, in index order.  P is
+    // every CU (or the V pairs if fewer; tests: `per` layers' worth); the chunk count K minimises the estimate
+    // rounds x (steps of a chunk x ~3 us + ~15 us of hand-over for K > 1), rounds = ceil(K V / P): B = 512 (V = 320):
+    // K = 4 -> 5 rounds of 64 steps instead of 2 passes of 251; B = 1536 (V = 960): K = 1 -> 4 passes instead of the
+    // 5 that whole layers per workgroup (2 x 96 of 256 CUs) took.
+    const int V = nl * n_tiles;
+    const int cap = g_lstm_wave_per > 0 ? per * n_tiles : num_cus();
+    const int P = V < cap ? V : cap;
+    int K = 1;
+    if (g_lstm_wave_chunk >= 2) {
+      K = cdiv(L, g_lstm_wave_chunk & ~1);
+    } else if (g_lstm_wave_chunk == 0 && state != nullptr && V > P) {
+      double best = 0.0;
+      for (int k = 1; k <= 8; ++k) {
+        const int Tk = (cdiv(L, k) + 1) & ~1;
+        if (k > 1 && Tk >= L) break;
+        const double est = (double)cdiv(k * V, P) * (Tk * 3.0 + (k > 1 ? 15.0 : 0.0));
+        if (best == 0.0 || est < best * 0.98) best = est, K = k;
+      }
     }
+    const int Tc = g_lstm_wave_chunk >= 2 ? (g_lstm_wave_chunk & ~1) : (cdiv(L, K) + 1) & ~1;
+    const bool chunked = K > 1 && state != nullptr && Tc < L;
+    LstmWaveArgs wa{};
+    for (int i = 0; i < nl; ++i) wa.wih[i] = wih[l0 + i], wa.whh[i] = whh[l0 + i], wa.bsum[i] = bsum[l0 + i];
+    hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)nl * n_tiles, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_lstm_wave<D>), dim3(P), dim3(512), lds, s, x, wa, nl, n_tiles, chunked ? Tc : Lfull, B, L, prog,
+                       chunked ? state : (float*)nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
   }
   return hipSuccess;
 }
