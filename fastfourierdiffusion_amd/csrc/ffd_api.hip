@@ -190,7 +190,7 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
-    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 8192,
+    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1 << 30,
     g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1;
     return FFD_OK;
   }
@@ -1376,8 +1376,11 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
         name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
       break;
     case FFD_K_LSTM_REC:
-      if (ls && lstm_wave_selected(B, m.d_model))  // every layer in one (or a few) launches: x W_ih^T + h W_hh^T
-        name = "k_lstm_wave", fl = m.num_layers * 2.0 * M * 8.0 * d * d, by = m.num_layers * 4.0 * (2.0 * M * d + 8.0 * d * d);
+      if (ls && lstm_wave_selected(B, m.d_model)) {  // every layer in one launch: x W_ih^T + h W_hh^T
+        // per launch: batches past a 16-sample tile per CU go in sub-batches (exact where B is a multiple of that)
+        const double Ml = (double)(B < lstm_wave_max_batch() ? B : lstm_wave_max_batch()) * L;
+        name = "k_lstm_wave", fl = m.num_layers * 2.0 * Ml * 8.0 * d * d, by = m.num_layers * 4.0 * (2.0 * Ml * d + 8.0 * d * d);
+      }
       else if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
         name = "k_lstm_mfma", fl = 2.0 * M * 8.0 * d * d, by = 4.0 * (2.0 * M * d + 8.0 * d * d);
       else if (ls)  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out

@@ -391,13 +391,13 @@ constexpr size_t lstm_mfma_lds(int D, int GRP) {
   return (size_t)(4 * NG * NTW * 64) * 16 + (size_t)GRP * 5 * 16 * (D + 2) * 4 + 16;
 }
 
-// Batch from which the batch-tiled kernel runs.  Where it applies (a 16-sample tile per CU, B <= 4096) k_lstm_wave is
-// the faster form at every batch (samples/s at 1000 steps, wave | mfma: B = 1536 387 | 180, 2048 513 | 238,
-// 3072 393 | 355, 4096 519 | 470) -- the crossover of round 2 (1792) was measured against the
-// one-sample-per-workgroup kernel the wavefront has replaced -- and between 4096 and 8192 samples the wavefront over
-// sub-batches of <= 4096 beats it too (B = 6144: 4096 + 2048 in 7.9 + 4.0 ms against 15.8).  From 8192 on the two
-// forms tie (0.70 of the matrix peak each) and the batch-tiled kernel keeps the path.
-int g_lstm_mfma_min_batch = 8192;
+// Batch from which the batch-tiled kernel runs: never by default since round 3.  The layer wavefront (k_lstm_wave, a
+// 16-sample tile per CU, larger batches in sub-batches of 4096) is the faster or equal form at every batch (samples/s at
+// 1000 steps, wave | mfma: B = 1536 480 | 180, 2048 514 | 238, 4096 520 | 470, 8192 518 | 516, 10000 513 | 310,
+// 12288 518 | 387, 16384 517 | 518): the two tie where the batch fills the batch-tiled kernel's
+// rounds exactly, and in between it runs a whole extra round.  ffd_tune "lstm_mfma_min_batch" selects it (the test
+// suite runs every LSTM golden through it as the cross-check of the wavefront).
+int g_lstm_mfma_min_batch = 1 << 30;
 int g_lstm_mfma_s = 0;  // 16-sample groups per workgroup: 0 = by batch, 1, 2
 
 bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }

@@ -313,7 +313,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
  *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
- *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs batch-tiled on the matrix core;
+ *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs on the batch-tiled k_lstm_mfma
+ *                                              (default 2^30: never; the layer wavefront is faster or equal everywhere);
  *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
  *   "lstm_wave" = 1 | 0 | 2                    LSTM below that batch: all layers as a wavefront of (16-sample tile, layer)
  *                                              workgroups (k_lstm_wave), or the per-layer kernels (0); 2 = at every

@@ -448,8 +448,8 @@ def test_lstm_full_batch_properties(ffd):
 
 def test_lstm_production_batch_selection(ffd):
     """BASELINE configs[3] shape at the batches the production selection (no ffd_tune here) hands to its two large-batch
-    forms: B = 2048 and B = 4352 to the layer wavefront (k_lstm_wave: a 16-sample tile per CU, larger batches in
-    sub-batches of 4096), B = 8192 (only its kernel class is checked here) to the batch-tiled recurrence (k_lstm_mfma).  Sample independence against small-batch evaluations for three picks, a
+    form, the layer wavefront (k_lstm_wave: a 16-sample tile per CU, larger batches in sub-batches of 4096; the
+    batch-tiled k_lstm_mfma is the cross-check kernel of the test suite since round 3): B = 2048 and B = 4352.  Sample independence against small-batch evaluations for three picks, a
     two-sample slice against the oracle, and the kernel class bench.py would report."""
     import ctypes as C
 
@@ -466,7 +466,8 @@ def test_lstm_production_batch_selection(ffd):
         fl, by = C.c_double(), C.c_double()
         assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, B, 0, C.byref(fl), C.byref(by)) == kname
         assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 512, 0, C.byref(fl), C.byref(by)) == b"k_lstm_wave"
-        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 8192, 0, C.byref(fl), C.byref(by)) == b"k_lstm_mfma"
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_LSTM_REC, 8192, 0, C.byref(fl), C.byref(by)) == b"k_lstm_wave"
+        assert fl.value == c["NL"] * 2.0 * 4096 * c["L"] * 8.0 * c["d"] ** 2  # per launch: a sub-batch of 4096
         for b in (0, B // 2 - 1, B - 1):
             one = m(batch_of(x[b:b + 1].cuda(), 0.45)).cpu()
             assert rel_err(out[b:b + 1], one) < 2e-6, (B, b)
@@ -1220,7 +1221,7 @@ def test_lstm_wavefront_more_layers_than_a_launch_holds(ffd):
 
 @pytest.fixture
 def lstm_mfma(ffd):
-    """Force the batch-tiled MFMA recurrence (k_lstm_mfma, selected for B >= 8192 in production) on small batches."""
+    """Force the batch-tiled MFMA recurrence (k_lstm_mfma: not selected in production since round 3, kept as the cross-check of the wavefront) on small batches."""
     from fastfourierdiffusion_amd import _native as N
 
     lib = N.lib()
@@ -1229,7 +1230,7 @@ def lstm_mfma(ffd):
         assert lib.ffd_tune(b"lstm_mfma_min_batch", 1) == 0 and lib.ffd_tune(b"lstm_mfma_s", s) == 0
 
     yield force
-    assert lib.ffd_tune(b"lstm_mfma_min_batch", 8192) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
+    assert lib.ffd_tune(b"lstm_mfma_min_batch", 1 << 30) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
 
 
 @pytest.mark.parametrize("s_tiles", [1, 2])
