@@ -1522,4 +1522,79 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   return FFD_OK;
 }
 
+int ffd_probe_attn(ffd_ctx* ctx, int B, int n_recompute, double warm_seconds, int iters, float* ms_out,
+                   unsigned long long* raw_out, int raw_capacity, int* nrec_out, void* stream) {
+  if (!ctx) return FFD_ERR_INVALID;
+  int rc = check_ready(ctx, B);
+  if (rc) return rc;
+  const ffd_model_desc& m = ctx->desc;
+  if (m.kind != FFD_MODEL_TRANSFORMER) return ctx->fail(FFD_ERR_UNSUPPORTED, "no attention in this backbone");
+  if (!ms_out || iters < 1 || !(warm_seconds >= 0.0) || warm_seconds > 30.0) return ctx->fail(FFD_ERR_INVALID, "bad argument");
+  if (!ctx->packed[0].aw_full) return ctx->fail(FFD_ERR_UNSUPPORTED, "no fused attention kernel for this shape");
+  const int L = m.max_len, d = m.d_model, H = m.n_head, hd = d / H;
+  if (n_recompute > L) return ctx->fail(FFD_ERR_INVALID, "n_recompute=%d outside [-1,%d]", n_recompute, L);
+  enum { STD, PURE, MIXED } mode = STD;
+  if (n_recompute >= 0 && (double)n_recompute <= 0.8 * (double)L) mode = n_recompute == 0 ? PURE : MIXED;
+  if (mode != STD && !(ctx->cache_enabled && ctx->table_allocated))
+    return ctx->fail(FFD_ERR_STATE, "cached modes need ffd_cache_enable and one full step (the tables)");
+  HIPCHECK(hipSetDevice(ctx->device));
+  if ((rc = ensure_workspace(ctx, B))) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t M = (size_t)B * L;
+  hipLaunchKernelGGL(k_fill_hash, dim3(1024), dim3(256), 0, s, ctx->h1, M * d, 0x9E3779B9u);  // random rows
+  HIPCHECK(hipGetLastError());
+  const LayerPacked& pk = ctx->packed[0];
+  const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L, B) : 1;
+  const float* pack = hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
+  const int n_own = mode == PURE ? 0 : mode == MIXED ? n_recompute : L;
+  // (MIXED: the recomputed rows of batch element 0 are NOT written back -- the probe leaves the tables as they are)
+  auto launch = [&](unsigned long long* st) {
+    return launch_qkv_attention(ctx->h1, pack, hpw, mode == PURE, mode != STD ? ctx->kt : nullptr,
+                                mode != STD ? ctx->vt : nullptr, nullptr, nullptr, ctx->attn, B, L, d, hd, n_own, s, st);
+  };
+  hipEvent_t e0, e1;
+  HIPCHECK(hipEventCreate(&e0));
+  HIPCHECK(hipEventCreate(&e1));
+  HIPCHECK(hipEventRecord(e0, s));
+  double elapsed = 0.0;
+  do {
+    for (int i = 0; i < 20; ++i) HIPCHECK(launch(nullptr));
+    HIPCHECK(hipEventRecord(e1, s));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    elapsed = ms * 1e-3;
+  } while (elapsed < warm_seconds);
+  HIPCHECK(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) HIPCHECK(launch(nullptr));
+  HIPCHECK(hipEventRecord(e1, s));
+  HIPCHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_out = ms / iters;
+  if (nrec_out) *nrec_out = 0;
+  if (raw_out && raw_capacity > 0) {
+    const size_t nwave = (size_t)B * H * 4;  // upper bound: at most 4 waves per (sample, head) workgroup / head pair
+    unsigned long long* stamps = nullptr;
+    HIPCHECK(hipMalloc((void**)&stamps, sizeof(unsigned long long) * 16 * nwave));
+    HIPCHECK(hipMemsetAsync(stamps, 0, sizeof(unsigned long long) * 16 * nwave, s));
+    hipError_t e = launch(stamps);
+    if (e != hipSuccess) {
+      (void)hipFree(stamps);
+      return ctx->fail(FFD_ERR_UNSUPPORTED, "no stamped twin of the attention kernel for this shape / mode");
+    }
+    std::vector<unsigned long long> h(16 * nwave);
+    HIPCHECK(hipMemcpyAsync(h.data(), stamps, sizeof(unsigned long long) * 16 * nwave, hipMemcpyDeviceToHost, s));
+    HIPCHECK(hipStreamSynchronize(s));
+    (void)hipFree(stamps);
+    int used = 0;
+    for (size_t i = 0; i < nwave && used < raw_capacity; ++i)
+      if (h[16 * i + 1] != 0) memcpy(raw_out + 16 * (size_t)used++, &h[16 * i], sizeof(unsigned long long) * 16);
+    if (nrec_out) *nrec_out = used;
+  }
+  return FFD_OK;
+}
+
 }  // extern "C"

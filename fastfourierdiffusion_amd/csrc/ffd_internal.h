@@ -187,7 +187,7 @@ int num_cus();  // compute units of the current device (256 on MI355X); ffd_ffn.
 extern int g_attn_hpw;
 hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
                                 const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
-                                int n_own, hipStream_t s);
+                                int n_own, hipStream_t s, unsigned long long* stamp = nullptr);
 extern int g_attn_qg;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]

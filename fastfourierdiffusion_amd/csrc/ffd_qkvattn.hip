@@ -38,6 +38,13 @@ __device__ __forceinline__ f32x2 pk_fma_hi(f32x2 p, f32x2 v, f32x2 acc) {
   return acc;
 }
 
+// Diagnostics (STAMP instances only; ffd_probe_attn): per-wave record of 16 x u64 in a buffer nothing else reads --
+// [0] 100 MHz real time at entry, shader-clock stamps [1] entry, [2] projection begin (x requested, weights staged),
+// [3] projection end, [4] attention begin (tables / norms done), [5] attention end, [6] exit, then shader cycles summed
+// over the wave's key tiles: [7] K fragments + QK^T until the scores are readable, [8] mask + softmax, [9] P.V;
+// [10] key tiles walked, [11] hardware id (HW_ID), [12] 100 MHz real time at exit.
+#define FFD_STAMP_T() ((unsigned long long)__builtin_amdgcn_s_memtime())
+
 // ---- weight pack ---------------------------------------------------------------------------------
 // awp[h][ct][step4][lane][4]: the B operand of k-step (4*step4 + i) for lane (n = lane & 15, q = lane >> 4):
 //   full 16-chunks j < D/16 : k = 16 j + 4 q + i          (step4 = j)
@@ -127,11 +134,13 @@ __device__ __forceinline__ void tile_norms(const float* kts, const float* qts, f
 // projecting the whole head but attending only nwaves/kspl q-tiles, with the key range of a q-tile cut into `kspl`
 // pieces over the waves (flash-decoding).  The pieces (reference exponent, row sum, unnormalised output) meet in
 // LDS and are merged in piece order, so the result does not depend on timing.
-template <int D, int HD, int QG, int NCT, bool SPLIT = false>
+template <int D, int HD, int QG, int NCT, bool SPLIT = false, bool STAMP = false>
 __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
-    int B, int L, int n_own, int q_only, int qsplit, int kspl) {
+    int B, int L, int n_own, int q_only, int qsplit, int kspl, unsigned long long* __restrict__ stamp) {
+  unsigned long long st_t[7] = {0, 0, 0, 0, 0, 0, 0}, st_qk = 0, st_sm = 0, st_pv = 0, st_n = 0;
+  if constexpr (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime(), st_t[1] = FFD_STAMP_T();
   constexpr int H = D / HD;
   constexpr int KST = (HD + 1) / 2;
   constexpr int KSX = (HD + 2) / 2;
@@ -212,6 +221,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     for (int u = 0; u < PFX; ++u)  // unconditional (tile index clamped): conditional loads would force vmcnt(0) waits
       load_x(min(wave + u * nwaves, TT - 1), xa[u], xr[u]);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) st_t[2] = FFD_STAMP_T();
     // Straight-line code (full unroll, forward exits only): a loop back-edge would make the compiler wait for
     // *all* outstanding loads at every tile (vmcnt(0)), which defeats the ring.  MAXT tiles per wave cover
     // L <= 512 with 4 waves.
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       }
     }
   }
+  if constexpr (STAMP) st_t[3] = FFD_STAMP_T();
   // rows served by the shared tables (PURE: all of them; MIXED: tokens >= n_own) overwrite / fill K^T and V
   if (kt != nullptr) {
     if (!q_only && n_own > 0) __syncthreads();  // MIXED: the projection wrote these rows first
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   }
 
   __syncthreads();  // the tile norms
+  if constexpr (STAMP) st_t[4] = FFD_STAMP_T();
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -359,6 +371,8 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
 #pragma unroll 1
     for (int t = t_lo; t < t_hi; ++t) {
+      unsigned long long st_a = 0;
+      if constexpr (STAMP) st_a = FFD_STAMP_T();
       float kf[KSX];
       const float kn2 = nrm[t];
 #pragma unroll
@@ -383,6 +397,12 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll
       for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (STAMP) {  // the stamp follows an instruction that reads the last score tile: QK^T has retired
+        asm volatile("v_mov_b32 %0, %0" : "+v"(sc[QG - 1][15]));
+        const unsigned long long n = FFD_STAMP_T();
+        st_qk += n - st_a, st_a = n, ++st_n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (32 * t + 32 > L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -431,6 +451,12 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
           lsum[g] += f32x2{p0, p1};
         }
       }
+      if constexpr (STAMP) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long n = FFD_STAMP_T();
+        st_sm += n - st_a, st_a = n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         f32x2 vv[4];
@@ -447,7 +473,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (STAMP) {
+        __builtin_amdgcn_sched_barrier(0);
+        st_pv += FFD_STAMP_T() - st_a;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    if constexpr (STAMP) st_t[5] = FFD_STAMP_T();
     if constexpr (SPLIT) {
       constexpr int PS = 2 + 2 * HP;  // per query row: reference exponent, row sum, unnormalised output
       float* part = lds + (size_t)Lp * (8 + 4 * KST);  // [wave][32][PS]
@@ -506,6 +538,16 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
     }
   }
+  if constexpr (STAMP) {
+    if (lane == 0 && stamp != nullptr) {
+      unsigned long long* r = stamp + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 16;
+      st_t[6] = FFD_STAMP_T();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) r[i] = st_t[i];
+      r[7] = st_qk, r[8] = st_sm, r[9] = st_pv, r[10] = st_n, r[11] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+      r[12] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 // ---- multi-head variant ------------------------------------------------------------------------------
@@ -517,11 +559,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 // staged once in LDS and read as the MFMA B operand from there.  Two heads = 4 waves, one per SIMD: a 6-wave
 // workgroup (3 heads) leaves the CU with a single resident workgroup (two of its waves land on SIMDs 0 and 1,
 // so a second one never fits at 3 waves per SIMD) and was slower.
-template <int D, int HD, int HPW, int QG, int NCT>
+template <int D, int HD, int HPW, int QG, int NCT, bool STAMP = false>
 __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
-    int B, int L, int n_own, int q_only) {
+    int B, int L, int n_own, int q_only, unsigned long long* __restrict__ stamp) {
+  unsigned long long st_t[7] = {0, 0, 0, 0, 0, 0, 0}, st_qk = 0, st_sm = 0, st_pv = 0, st_n = 0;
+  if constexpr (STAMP) st_t[0] = __builtin_amdgcn_s_memrealtime(), st_t[1] = FFD_STAMP_T();
   constexpr int H = D / HD;
   constexpr int NG = H / HPW;
   constexpr int KST = (HD + 1) / 2;
@@ -608,6 +652,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       fe[ct] = f - reg * HD;
     }
     __syncthreads();
+    if constexpr (STAMP) st_t[2] = FFD_STAMP_T();
 #pragma unroll
     for (int it = 0; it < MAXT; ++it) {
       const int tt = wave + it * NW;
@@ -692,6 +737,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       }
     }
   }
+  if constexpr (STAMP) st_t[3] = FFD_STAMP_T();
   // this wave's head for the rest of the kernel
   const int hh = wave >> 1, gw = wave & 1;
   const int h = hg * HPW + hh;
@@ -748,6 +794,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   }
 
   __syncthreads();  // the tile norms
+  if constexpr (STAMP) st_t[4] = FFD_STAMP_T();
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -786,6 +833,8 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     }
 #pragma unroll 1
     for (int t = 0; t < KT; ++t) {
+      unsigned long long st_a = 0;
+      if constexpr (STAMP) st_a = FFD_STAMP_T();
       float kf[KSX];
       const float kn2 = nrm[t];
 #pragma unroll
@@ -810,6 +859,12 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
 #pragma unroll
       for (int r = 0; r < PF; ++r) load_v(r, kbase, vb[r]);
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (STAMP) {  // the stamp follows an instruction that reads the last score tile: QK^T has retired
+        asm volatile("v_mov_b32 %0, %0" : "+v"(sc[QG - 1][15]));
+        const unsigned long long n = FFD_STAMP_T();
+        st_qk += n - st_a, st_a = n, ++st_n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (32 * t + 32 > L) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -858,6 +913,12 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
           lsum[g] += f32x2{p0, p1};
         }
       }
+      if constexpr (STAMP) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long n = FFD_STAMP_T();
+        st_sm += n - st_a, st_a = n;
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         f32x2 vv[4];
@@ -874,7 +935,13 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (STAMP) {
+        __builtin_amdgcn_sched_barrier(0);
+        st_pv += FFD_STAMP_T() - st_a;
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    if constexpr (STAMP) st_t[5] = FFD_STAMP_T();
 #pragma unroll
     for (int g = 0; g < QG; ++g) {
       float l = lsum[g].x + lsum[g].y;
@@ -896,32 +963,52 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       }
     }
   }
+  if constexpr (STAMP) {
+    if (lane == 0 && stamp != nullptr) {
+      unsigned long long* r = stamp + ((size_t)blockIdx.x * NW + wave) * 16;
+      st_t[6] = FFD_STAMP_T();
+#pragma unroll
+      for (int i = 0; i < 7; ++i) r[i] = st_t[i];
+      r[7] = st_qk, r[8] = st_sm, r[9] = st_pv, r[10] = st_n, r[11] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+      r[12] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 template <int D, int HD, int HPW, int QG, int NCT>
 static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
-                              float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
+                              float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s,
+                              unsigned long long* stamp) {
   constexpr int KST = (HD + 1) / 2;
   constexpr int S4 = (D + 15) / 16;
   const int KT = (L + 31) / 32;
   const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2 * KT) * sizeof(float);
-  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
   if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
+  if constexpr (D == 72 && HD == 6) {  // (the stamped twin exists for the headline shape only)
+    if (stamp != nullptr) {
+      hipLaunchKernelGGL((k_qkv_attention_mh<D, HD, HPW, QG, NCT, true>), dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds,
+                         s, x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, stamp);
+      return hipGetLastError();
+    }
+  }
+  if (stamp != nullptr) return hipErrorInvalidValue;
+  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
   hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
-                     n_own, q_only);
+                     n_own, q_only, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
 
 // 2 heads per workgroup, 2 waves per head: L <= 192 (<= 3 q-tiles per wave, 12 token tiles over 4 waves)
 template <int D, int HD>
 static hipError_t launch_mh2(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
-                             float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s) {
+                             float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s,
+                             unsigned long long* stamp) {
   constexpr int NF = (2 * 3 * HD + 15) / 16, NQ = (2 * HD + 15) / 16;
   const int QG = cdiv((L + 31) / 32, 2);
 #define FFD_MH(qg)                                                                                                   \
   if (QG == qg)                                                                                                      \
-    return q_only ? launch_mh_t<D, HD, 2, qg, NQ>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s)            \
-                  : launch_mh_t<D, HD, 2, qg, NF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+    return q_only ? launch_mh_t<D, HD, 2, qg, NQ>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s, stamp)     \
+                  : launch_mh_t<D, HD, 2, qg, NF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
   FFD_MH(1) FFD_MH(2) FFD_MH(3)
 #undef FFD_MH
   return hipErrorInvalidValue;
@@ -929,15 +1016,24 @@ static hipError_t launch_mh2(const float* x, const float* awp, int q_only, const
 
 template <int D, int HD, int QG, int NCT>
 static hipError_t launch_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
-                           float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s) {
+                           float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s,
+                           unsigned long long* stamp = nullptr) {
   constexpr int KST = (HD + 1) / 2;
   const int KT = (L + 31) / 32;
   const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)2 * KT) * sizeof(float);
   int nwaves = cdiv(KT, QG);
   if (nwaves > 4) nwaves = 4;
   if (cdiv(2 * KT, nwaves) > 8) return hipErrorInvalidValue;  // the projection loop is unrolled for <= 8 token tiles per wave
+  if constexpr (D == 72 && HD == 6 && NCT == 2) {  // (the stamped twin exists for the headline model's full pack only)
+    if (stamp != nullptr) {
+      hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT, false, true>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x,
+                         awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, 1, 1, stamp);
+      return hipGetLastError();
+    }
+  }
+  if (stamp != nullptr) return hipErrorInvalidValue;
   hipLaunchKernelGGL((k_qkv_attention<D, HD, QG, NCT>), dim3(B * (D / HD)), dim3(64 * nwaves), lds, s, x, awp, kt, vt,
-                     kt_out, vt_out, out, B, L, n_own, q_only, 1, 1);
+                     kt_out, vt_out, out, B, L, n_own, q_only, 1, 1, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
 
@@ -951,7 +1047,7 @@ static hipError_t launch_split_t(const float* x, const float* awp, const float* 
   const int qsplit = cdiv(KT, 4 / kspl);
   const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP) + (size_t)2 * KT) * sizeof(float);
   hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
-                     vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl);
+                     vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
 
@@ -972,13 +1068,15 @@ int qkv_attention_small_split(int B, int H, int L) {
 
 template <int D, int HD>
 static hipError_t launch_dh(const float* x, const float* awp, int q_only, const float* kt, const float* vt,
-                            float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s) {
+                            float* kt_out, float* vt_out, float* out, int B, int L, int n_own, hipStream_t s,
+                            unsigned long long* stamp) {
   constexpr int NCTF = (3 * HD + 15) / 16;
   const int QT = (L + 31) / 32;
-  if (const int kspl = qkv_attention_small_split(B, D / HD, L))
+  if (const int kspl = stamp ? 0 : qkv_attention_small_split(B, D / HD, L))
     return q_only ? launch_split_t<D, HD, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, kspl, s)
                   : launch_split_t<D, HD, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, kspl, s);
   if (q_only) {
+    if (stamp != nullptr) return hipErrorInvalidValue;
     if (QT == 1) return launch_t<D, HD, 1, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
     if (QT % 3 == 0) return launch_t<D, HD, 3, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
     if constexpr (HD <= 6) {
@@ -986,15 +1084,15 @@ static hipError_t launch_dh(const float* x, const float* awp, int q_only, const 
     }
     return launch_t<D, HD, 2, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);
   }
-  if (g_attn_qg == 2) return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
-  if (g_attn_qg == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
-  if (QT == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
-  if (QT % 3 == 0) return launch_t<D, HD, 3, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  if (g_attn_qg == 2) return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
+  if (g_attn_qg == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
+  if (QT == 1) return launch_t<D, HD, 1, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
+  if (QT % 3 == 0) return launch_t<D, HD, 3, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
   // long sequences: four q-tiles per wave share every K^T / V read (L = 512: 2422 -> 2286 us against two per wave)
   if constexpr (HD <= 6) {  // (hd = 8 would spill at four query groups)
-    if (QT % 4 == 0 && QT >= 16) return launch_t<D, HD, 4, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+    if (QT % 4 == 0 && QT >= 16) return launch_t<D, HD, 4, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
   }
-  return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s);
+  return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
 }
 
 int g_attn_fused = 1;  // 1: fused in-projection + attention where a kernel exists (ffd_tune "attn_fused")
@@ -1017,16 +1115,16 @@ int qkv_attention_hpw(int D, int hd, int L, int B) {
 
 hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
                                 const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
-                                int n_own, hipStream_t s) {
+                                int n_own, hipStream_t s, unsigned long long* stamp) {
   if (B <= 0) return hipSuccess;
   if (hpw == 2) {
-    if (D == 72 && hd == 6) return launch_mh2<72, 6>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
-    if (D == 60 && hd == 5) return launch_mh2<60, 5>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
-    if (D == 48 && hd == 4) return launch_mh2<48, 4>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+    if (D == 72 && hd == 6) return launch_mh2<72, 6>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s, stamp);
+    if (D == 60 && hd == 5) return launch_mh2<60, 5>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s, stamp);
+    if (D == 48 && hd == 4) return launch_mh2<48, 4>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s, stamp);
     return hipErrorInvalidValue;
   }
 #define FFD_QA(dd, hh) \
-  if (D == dd && hd == hh) return launch_dh<dd, hh>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s);
+  if (D == dd && hd == hh) return launch_dh<dd, hh>(x, awp, q_only, kt, vt, kt_out, vt_out, out, B, L, n_own, s, stamp);
   FFD_QA(72, 6)
   FFD_QA(60, 5)
   FFD_QA(24, 6)

@@ -377,6 +377,18 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream);
 int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out,
                         unsigned long long* raw_out, int raw_capacity, int* nwg_out, void* stream);
 
+/* Diagnostic + benchmark helper for the fused in-projection + attention launch of layer 0 (ffd_qkvattn.hip) at batch B
+ * on random rows (replaces nothing in the reference: measurement scaffolding for cached_transformer.py:228-311's
+ * kernel).  n_recompute < 0: plain layer; otherwise the E2-CRF mode of that recompute-set size (needs ffd_cache_enable
+ * and one FULL step for the tables).  Launches it back to back for `warm_seconds`, times `iters` launches with HIP
+ * events (*ms_out = milliseconds per launch), then -- when raw_out != NULL -- once more as its stamped twin (d_model 72,
+ * head_dim 6 only): up to raw_capacity records of 16 x u64 per WAVE: [0] 100 MHz real time at entry, shader-clock
+ * (s_memtime) stamps [1] entry, [2] projection begin, [3] projection end, [4] attention begin, [5] attention end,
+ * [6] exit, shader cycles summed over the wave's key tiles [7] K fragments + QK^T, [8] mask + softmax, [9] P.V,
+ * [10] key tiles walked, [11] HW_ID, [12] 100 MHz real time at exit; *nrec_out = records written.  Synchronous. */
+int ffd_probe_attn(ffd_ctx* ctx, int B, int n_recompute, double warm_seconds, int iters, float* ms_out,
+                   unsigned long long* raw_out, int raw_capacity, int* nrec_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

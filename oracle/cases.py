@@ -187,3 +187,20 @@ TWO_SAMPLER_CASE = dict(name="two_samplers", **_SMALL, sde="vp", sde_kwargs=VP, 
 # cmd/sample.py:107-113 (X * std + mean, then idft) and its ingest twin datamodules.py:42-62 ((dft(X) - mean) / std).
 # (L, C, B, seed)
 AFFINE_FFT_CASES = [(187, 1, 4, 141), (251, 4, 3, 142), (100, 3, 2, 143), (512, 8, 2, 144)]
+
+
+# ---- round 4 (g13) -----------------------------------------------------------------------------------
+# BASELINE configs[3] at its full length (NASA charge, LSTM backbone, 1000 steps), the reference's CLASS-default
+# transformer (score_models.py:31-33: d_model 60, 3 layers, 12 heads) at the ECG length, and the reference's default
+# sample_batch_size = 50 (cmd/conf/sampler/default.yaml:3) with the cache on.
+_D60_ECG = dict(kind="transformer", d=60, H=12, NL=3, L=187, C=1)
+ROUND4_TRAJ_CASES = [
+    dict(name="traj_nasa_lstm_1000", **_NASA_LSTM, sde="vp", sde_kwargs=VP, fourier=True, B=2, num_samples=2, N=1000,
+         use_cache=False, wseed=45, zseed=151),
+    dict(name="traj_d60_ecg_100", **_D60_ECG, sde="vp", sde_kwargs=VP, fourier=True, B=3, num_samples=3, N=100,
+         use_cache=False, wseed=53, zseed=152),
+    dict(name="traj_d60_ecg_cache_30", **_D60_ECG, sde="ve", sde_kwargs=VE, fourier=True, B=2, num_samples=4, N=30,
+         use_cache=True, cache_kwargs={}, wseed=53, zseed=153),
+    dict(name="traj_ecg_b50_cache_12", **_ECG, sde="vp", sde_kwargs=VP, fourier=True, B=50, num_samples=50, N=12,
+         use_cache=True, cache_kwargs={}, wseed=42, zseed=154),
+]

@@ -211,10 +211,32 @@ def gen_round2(ns) -> None:
     np.savez_compressed(os.path.join(OUT, "g12_round2.npz"), **g)
 
 
+def gen_round4(ns) -> None:
+    """G13: the full-length LSTM trajectory of BASELINE configs[3], the reference's class-default transformer
+    (d_model 60) at the ECG length, and a batch of the reference's default sample_batch_size (50) with the cache on."""
+    g = {}
+    for c in cases.ROUND4_TRAJ_CASES:
+        m, sch = make_model(ns, c)
+        B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+        nb = max(1, c["num_samples"] // B)
+        stream = synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"])
+        sampler = ns.DiffusionSampler(score_model=m, sample_batch_size=B, use_cache=c["use_cache"],
+                                      cache_kwargs=dict(c.get("cache_kwargs", {})))
+        with injected_noise(stream):
+            out = sampler.sample(num_samples=c["num_samples"], num_diffusion_steps=N)
+        g[c["name"]] = out.numpy()
+        g[c["name"] + "_ts"] = sch.timesteps.numpy().copy()
+        print(c["name"], out.shape, float(out.abs().max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g13_round4.npz"), **g)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
+    if "--only-round4" in sys.argv:  # just G13
+        gen_round4(ns)
+        return
     if "--only-round2" in sys.argv:  # just G12
         gen_round2(ns)
         return
@@ -350,6 +372,7 @@ def main() -> None:
     gen_freqca(ns)
     gen_extra_traj(ns)
     gen_round2(ns)
+    gen_round4(ns)
 
     with open(os.path.join(OUT, "META.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from the unmodified reference at /root/reference\n")

@@ -299,3 +299,21 @@ def test_affine_fft_golden(golden, case):
     g = golden["g12_round2"]
     assert rel_err(O.unstandardize_idft(x, mean, std), g[f"unstd_idft_L{L}_C{C}"]) < TOL_KERNEL
     assert rel_err(O.dft_standardize(x, mean, std), g[f"dft_std_L{L}_C{C}"]) < TOL_KERNEL
+
+
+# ---- G13 (round 4): BASELINE configs[3] at its full 1000 steps, the class-default d_model 60, sample_batch_size 50 ----
+@pytest.mark.slow
+@pytest.mark.parametrize("c", cases.ROUND4_TRAJ_CASES, ids=lambda c: c["name"])
+def test_round4_traj_golden(golden, c):
+    torch.set_num_threads(8)
+    sd = make_sd(c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    nb = max(1, c["num_samples"] // B)
+    noise = (torch.from_numpy(z) for z in synthetic.noise_stream((B, L, C), nb * (N + 1), c["zseed"]))
+    ck = c.get("cache_kwargs", {})
+    out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=c["sde"],
+                   sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"], num_samples=c["num_samples"],
+                   batch_size=B, num_steps=N, noise=noise, use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10))
+    ref = golden["g13_round4"][c["name"]]
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
