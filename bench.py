@@ -44,6 +44,17 @@ if ROOT not in sys.path:
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the opt-in split FFN keeps 6 bf16 products per fp32 one)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2, dense fp32 matrix peak
+def _ref_over_port():
+    """Build-container measurement (tools/time_reference_cpu.py, committed): B = 32 step time of the CPU baseline's port
+    (oracle with the stock nn.TransformerEncoder backbone) over the UNMODIFIED reference's -- how much faster the
+    reference itself is than the port that is timed on this box."""
+    try:
+        rt = json.load(open(os.path.join(ROOT, "profiles", "r04_reference_cpu_timing.json")))["step_b32_ms"]
+        return rt["oracle_stock"] / (0.5 * (rt["reference"] + rt["reference_again"]))
+    except Exception:
+        return None
+
+
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
 WORKLOADS = {
@@ -212,7 +223,10 @@ def host_cores() -> int:
 
 def cpu_baseline(sd, L, Cn, NL, H, kind):
     """The oracle (CPU restatement of the reference path, torch-CPU fp32, all host cores)
-    on a bounded sample of the same workload."""
+    on a bounded sample of the same workload.  The transformer backbone is torch's stock nn.TransformerEncoder built as
+    the reference builds it (score_models.py:61-66), so that the baseline runs on the fused encoder-layer path the
+    reference's own CPU run takes and at its speed (profiles/r04_reference_cpu_timing.json: within a few per cent of
+    the unmodified reference; the explicit restatement used for parity is ~1.5x slower)."""
     import torch
 
     from oracle import ffd_oracle as O
@@ -233,13 +247,15 @@ def cpu_baseline(sd, L, Cn, NL, H, kind):
         if kind == "lstm":
             score = O.lstm_score_forward(x, t, sdt, NL)
         else:
-            score = O.score_forward(x, t, sdt, NL, H)
+            score = O.score_forward_stock(x, t, sdt, NL, H)
         x = O.vp_step(x, score, torch.randn(B, L, Cn, generator=g), tv, G, dt)
         if i >= warm:
             t_acc += time.perf_counter() - t0
     s_per_step = t_acc / steps
     return {"value": B / (1000.0 * s_per_step), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32), B={B}, {steps} of 1000 steps timed after {warm} warm-up, x(1000/{steps})",
+            "sample": f"oracle (torch-CPU fp32{'' if kind == 'lstm' else ', stock nn.TransformerEncoder backbone = the fused path the reference runs'}), B={B}, {steps} of 1000 steps timed after {warm} warm-up, x(1000/{steps})",
+            "reference_speed_over_port": None if kind == "lstm" else _ref_over_port(),
+            "reference_speed_source": "profiles/r04_reference_cpu_timing.json (unmodified reference vs this port, B=32 step, build container)",
             "ms_per_step": s_per_step * 1e3}
 
 
@@ -589,12 +605,20 @@ def main() -> None:
             hb["contract"] = {"reference_ratio": 1.12, "reference_ratio_source": "notebooks/ablation_cache_test.ipynb:277-278 "
                               "(15.78 s vs 17.70 s, Apple mps, B=1, 20 x 100 steps)", "gpu_ratio": hb["off_over_on"],
                               "gpu_over_reference": hb["off_over_on"] / 1.12,
-                              "within_5_percent": abs(hb["off_over_on"] / 1.12 - 1.0) <= 0.05}
-            rpath = os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json")
+                              "within_5_percent": abs(hb["off_over_on"] / 1.12 - 1.0) <= 0.05,
+                              "why_not_the_same_box_cpu_ratio": "BASELINE.md reads 'the reference's measured ratio on the same "
+                              "box'; the reference cannot run on this box's GPU (CUDA / mps only) and on a CPU its cache is a "
+                              "SLOW-DOWN (0.84 median in the build container, 0.90 for the oracle on this box's cores: the "
+                              "explicit cached layers lose torch's fused encoder path), so a device ratio > 1 can only be "
+                              "compared with the reference's own device ratio, the published 1.12; the CPU ratios are "
+                              "reported beside it (reference_cpu_timing, cpu_oracle), 20-30 % away by construction"}
+            rpath = os.path.join(ROOT, "profiles", "r04_reference_cpu_timing.json")
+            if not os.path.exists(rpath):
+                rpath = os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json")
             if os.path.exists(rpath):
                 rt = json.load(open(rpath))
                 hb["reference_cpu_timing"] = {
-                    "file": "profiles/r03_reference_cpu_timing.json", "threads": rt["threads"],
+                    "file": "profiles/" + os.path.basename(rpath), "threads": rt["threads"],
                     "num_samples": rt["num_samples"], "num_diffusion_steps": rt["num_diffusion_steps"],
                     "reference_off_over_on_per_rep": rt["harness_b1"]["reference"]["off_over_on_per_rep"],
                     "reference_off_over_on_median": rt["harness_b1"]["reference"]["off_over_on_median"],
@@ -625,7 +649,9 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:  # reported at N=1 only (a bounded ~25 s CPU sample)
             out["cpu_baseline"] = cpu_baseline(sd, L, Cn, model.num_layers, model.n_head,
                                                "lstm" if is_lstm else "transformer")
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            # (against the reference's own speed: the port's value x the measured reference / port ratio)
+            rop = out["cpu_baseline"].get("reference_speed_over_port") or 1.0
+            out["speedup_vs_cpu_baseline"] = value / (out["cpu_baseline"]["value"] * rop)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

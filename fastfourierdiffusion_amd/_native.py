@@ -106,6 +106,7 @@ SIGNATURES = {
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
     "ffd_probe_ffn_clock": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int), _P]),
+    "ffd_async_status": (C.c_int, [_P]),
     "ffd_probe_attn": (C.c_int, [_P, C.c_int, C.c_int, C.c_double, C.c_int, _F, C.POINTER(C.c_uint64), C.c_int,
                                  C.POINTER(C.c_int), _P]),
 }

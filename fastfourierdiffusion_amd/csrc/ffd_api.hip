@@ -82,6 +82,7 @@ struct ffd_ctx {
   float* temb_b = nullptr;  // (B, d) per-sample time embeddings (ffd_score_forward_ts)
   int* lstm_prog = nullptr;  // progress words of the LSTM layer wavefront
   size_t lstm_prog_ints = 0;
+  int* async_err = nullptr;  // host-mapped word a kernel's timed-out wait writes (k_lstm_wave); read by check_async
   float* lstm_state = nullptr;  // (tile, layer) state blocks of the time-chunked wavefront
   size_t lstm_state_floats = 0;
   float* ffn_part = nullptr;  // partial Y tiles of the small-M split FFN
@@ -121,8 +122,12 @@ struct ffd_ctx {
       return ctx->fail(FFD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
+static int g_fail_alloc_after = 0;  // tests: the n-th device allocation from now fails (ffd_tune "fail_alloc_after")
+
 static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
   *p = nullptr;
+  if (g_fail_alloc_after > 0 && --g_fail_alloc_after == 0)
+    return ctx->fail(FFD_ERR_NOMEM, "hipMalloc(%zu floats) failed: injected by ffd_tune(\"fail_alloc_after\")", nfloats);
   hipError_t e = hipMalloc((void**)p, nfloats * sizeof(float) + 256);
   if (e != hipSuccess) return ctx->fail(FFD_ERR_NOMEM, "hipMalloc(%zu floats) failed: %s", nfloats, hipGetErrorString(e));
   ctx->owned.push_back(*p);
@@ -131,17 +136,26 @@ static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
 
 // Replace a workspace buffer by a larger one: the old allocation is released after the stream has drained (workspaces
 // grow a handful of times; without this every growth kept the old buffer until ffd_destroy -- 3.6 GB for the q/k/v
-// regions at B = 8192, L = 512).
-static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats) {
+// regions at B = 8192, L = 512).  `cap` is the capacity that guards the buffer: it reads 0 from the moment the old
+// buffer is gone until the new one exists, so a failed growth (out of memory) leaves "nothing allocated", never a
+// capacity that vouches for a freed or null pointer.  Capacities shared by several buffers (ws_B, fwork_B, temb_cap)
+// are zeroed by the caller before the first regrow and set after the last.
+template <typename CapT>
+static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats, CapT* cap, CapT cap_value) {
   float* old = *p;
+  if (cap) *cap = 0;
+  *p = nullptr;
   if (old) {
     (void)hipDeviceSynchronize();
     auto it = std::find(ctx->owned.begin(), ctx->owned.end(), (void*)old);
     if (it != ctx->owned.end()) ctx->owned.erase(it);
     (void)hipFree(old);
   }
-  return dev_alloc(ctx, p, nfloats);
+  int rc = dev_alloc(ctx, p, nfloats);
+  if (rc == FFD_OK && cap) *cap = cap_value;
+  return rc;
 }
+static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats) { return dev_regrow<int>(ctx, p, nfloats, nullptr, 0); }
 
 static int g_fuse_tail = 1;
 
@@ -191,7 +205,7 @@ int ffd_tune(const char* key, int value) {
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1 << 30,
-    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1;
+    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
@@ -288,6 +302,16 @@ int ffd_tune(const char* key, int value) {
     g_lstm_wave_per = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "lstm_wave_fault")) {  // tests: unit (value - 1) of k_lstm_wave never publishes its progress
+    if (value < 0) return FFD_ERR_INVALID;
+    g_lstm_wave_fault = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "lstm_wave_spin_ms")) {  // time limit of one wait on a progress word
+    if (value < 1 || value > 20000) return FFD_ERR_INVALID;
+    g_lstm_wave_spin_ms = value;
+    return FFD_OK;
+  }
   if (!strcmp(key, "lstm_mfma_s")) {  // 16-sample tiles per workgroup of that kernel (0 = by batch)
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_lstm_mfma_s = value;
@@ -305,6 +329,11 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "attn_hpw")) {
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_attn_hpw = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "fail_alloc_after")) {  // tests: the n-th device allocation from now fails with FFD_ERR_NOMEM (0 = off)
+    if (value < 0) return FFD_ERR_INVALID;
+    g_fail_alloc_after = value;
     return FFD_OK;
   }
   if (!strcmp(key, "attn_fused")) {
@@ -407,6 +436,9 @@ int ffd_create(ffd_ctx** out, const ffd_model_desc* desc, int device) {
   HIPCHECK(hipMemcpy(ctx->G_dev, ctx->G_host.data(), sizeof(float) * m.max_len, hipMemcpyHostToDevice));
   rc = dev_alloc(ctx, &ctx->temb1, m.d_model);
   if (rc) return rc;
+  // (host memory the device writes through: readable by the host without a copy once the stream has drained)
+  HIPCHECK(hipHostMalloc((void**)&ctx->async_err, 64, hipHostMallocMapped));
+  memset(ctx->async_err, 0, 64);
   return FFD_OK;
 }
 
@@ -416,6 +448,7 @@ void ffd_destroy(ffd_ctx* ctx) {
   for (auto& kv : ctx->raw) (void)hipFree(kv.second.p);
   for (void* p : ctx->owned) (void)hipFree(p);
   for (hipEvent_t e : ctx->ev) (void)hipEventDestroy(e);
+  if (ctx->async_err) (void)hipHostFree(ctx->async_err);
   delete ctx;
 }
 
@@ -617,13 +650,13 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
   const size_t M = (size_t)B * m.max_len, d = m.d_model;
   HIPCHECK(hipSetDevice(ctx->device));
   int rc;
+  ctx->ws_B = 0;  // (nothing vouches for these buffers until all of them exist at the new size)
   if ((rc = dev_regrow(ctx, &ctx->h0, M * d))) return rc;
   if ((rc = dev_regrow(ctx, &ctx->score, M * m.n_channels))) return rc;
   if ((rc = dev_regrow(ctx, &ctx->temb_b, (size_t)B * d))) return rc;
   if (m.kind == FFD_MODEL_MLP) {
     if ((rc = dev_regrow(ctx, &ctx->h1, (size_t)B * d))) return rc;                  // ping-pong of the (B, d) state
-    if ((rc = dev_regrow(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
-    ctx->qkv_floats = (size_t)B * m.dim_feedforward;
+    if ((rc = dev_regrow(ctx, &ctx->qkv, (size_t)B * m.dim_feedforward, &ctx->qkv_floats, (size_t)B * m.dim_feedforward))) return rc;  // hidden (B, d_mlp)
   } else if (m.kind == FFD_MODEL_TRANSFORMER) {
     if ((rc = dev_regrow(ctx, &ctx->h1, M * d))) return rc;
     if ((rc = dev_regrow(ctx, &ctx->attn, M * d))) return rc;
@@ -636,10 +669,7 @@ static int ensure_workspace(ffd_ctx* ctx, int B) {
 
 static int ensure_qkv(ffd_ctx* ctx, size_t floats) {
   if (floats <= ctx->qkv_floats) return FFD_OK;
-  int rc = dev_regrow(ctx, &ctx->qkv, floats);
-  if (rc) return rc;
-  ctx->qkv_floats = floats;
-  return FFD_OK;
+  return dev_regrow(ctx, &ctx->qkv, floats, &ctx->qkv_floats, floats);
 }
 
 // one score evaluation; temb points at d floats on the device (temb_stride = 0: shared by the batch) or at a
@@ -676,25 +706,25 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
   if (m.kind == FFD_MODEL_LSTM) {
     TIMED(FFD_K_EMBED, launch_embed(x, ctx->raw["embedder.weight"].p, ctx->raw["embedder.bias"].p, nullptr, temb,
                                     temb_stride, ctx->h0, B, L, C, d, s));
-    if (lstm_wave_selected(B, d) && m.num_layers <= 64) {  // mid-size batches: the layers as a wavefront (ffd_lstm.hip)
-      const int Bw = B < lstm_wave_max_batch() ? B : lstm_wave_max_batch();  // samples per launch
-      const size_t need = (size_t)16 * cdiv(Bw, 16);
+    if (lstm_wave_selected(B, d) && m.num_layers <= 64 && lstm_wave_max_batch(L, d) >= 16) {  // mid-size batches: the layers as a wavefront (ffd_lstm.hip)
+      const int Bw = B < lstm_wave_max_batch(L, d) ? B : lstm_wave_max_batch(L, d);  // samples per launch
+      const size_t need = (size_t)16 + 16 * cdiv(Bw, 16);
       if (need > ctx->lstm_prog_ints) {
         float* pbuf = reinterpret_cast<float*>(ctx->lstm_prog);
-        if (int rc = dev_regrow(ctx, &pbuf, need)) return rc;
-        ctx->lstm_prog = reinterpret_cast<int*>(pbuf), ctx->lstm_prog_ints = need;
+        ctx->lstm_prog = nullptr;
+        if (int rc = dev_regrow(ctx, &pbuf, need, &ctx->lstm_prog_ints, need)) return rc;
+        ctx->lstm_prog = reinterpret_cast<int*>(pbuf);
       }
       const float *wih[64], *whh[64], *bs[64];
       for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].wih, whh[i] = ctx->lstm[i].whh, bs[i] = ctx->lstm[i].bsum;
       const size_t need_st = lstm_wave_state_floats(Bw, d, m.num_layers);
       if (need_st > ctx->lstm_state_floats) {
-        if (int rc = dev_regrow(ctx, &ctx->lstm_state, need_st)) return rc;
-        ctx->lstm_state_floats = need_st;
+        if (int rc = dev_regrow(ctx, &ctx->lstm_state, need_st, &ctx->lstm_state_floats, need_st)) return rc;
       }
       for (int b0 = 0; b0 < B; b0 += Bw) {  // (samples are independent: sub-batches of a tile per CU, one after the other)
         const int nb = B - b0 < Bw ? B - b0 : Bw;
         TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0 + (size_t)b0 * L * d, wih, whh, bs, m.num_layers, nb, L, d,
-                                               ctx->lstm_prog, ctx->lstm_state, s));
+                                               ctx->lstm_prog, ctx->lstm_state, ctx->async_err, s));
       }
     } else
     for (int i = 0; i < m.num_layers; ++i) {
@@ -777,8 +807,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       // small M: out-proj + LN1 recomputed per F split, FFN partials + a deterministic reduce / LN2 launch
       const size_t need = small_path_partial_floats(M, d, ns);
       if (need > ctx->ffn_part_floats) {
-        if (int rc = dev_regrow(ctx, &ctx->ffn_part, need)) return rc;
-        ctx->ffn_part_floats = need;
+        if (int rc = dev_regrow(ctx, &ctx->ffn_part, need, &ctx->ffn_part_floats, need)) return rc;
       }
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
     } else if (int snw = 0, sns = 0; !split_ffn && w.ring_op != nullptr && rows_slice_plan(M, d, F, &snw, &sns)) {
@@ -786,8 +815,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       // the reduce / LN2 launch (deterministic: the slices are added in order)
       const size_t need = rows_slice_floats(M, d, sns);
       if (need > ctx->ffn_part_floats) {
-        if (int rc = dev_regrow(ctx, &ctx->ffn_part, need)) return rc;
-        ctx->ffn_part_floats = need;
+        if (int rc = dev_regrow(ctx, &ctx->ffn_part, need, &ctx->ffn_part_floats, need)) return rc;
       }
       TIMED(FFD_K_FFN, launch_oproj_ffn_rows_sliced(ctx->attn, cur, w, ctx->ffn_part, alt, M, d, F, snw, sns, s));
       float* t = cur;
@@ -804,8 +832,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       if (nm) {  // mid-size M: 64-row tiles x F slices, partial tiles + the reduce / LN2 launch
         const size_t need = small_path_partial_floats(cdiv(M, 64) * 64, d, nm);
         if (need > ctx->ffn_part_floats) {
-          if (int rc = dev_regrow(ctx, &ctx->ffn_part, need)) return rc;
-          ctx->ffn_part_floats = need;
+          if (int rc = dev_regrow(ctx, &ctx->ffn_part, need, &ctx->ffn_part_floats, need)) return rc;
         }
         TIMED(FFD_K_FFN, launch_ffn_mid(alt, w, ctx->ffn_part, cur, M, d, F, nm, s));
       } else if (split_ffn) TIMED(FFD_K_FFN, launch_ffn_ln_split(alt, w, cur, M, d, F, s));
@@ -837,7 +864,21 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
   return FFD_OK;
 }
 
+// A kernel whose bounded wait ran out (k_lstm_wave's progress-word protocol) has left a code in ctx->async_err: the
+// results of that launch are void.  Reported once, by whichever entry point comes next (or ffd_async_status).
+static int check_async(ffd_ctx* ctx) {
+  if (!ctx->async_err) return FFD_OK;
+  const int code = *reinterpret_cast<volatile int*>(ctx->async_err);
+  if (code == 0) return FFD_OK;
+  *reinterpret_cast<volatile int*>(ctx->async_err) = 0;
+  return ctx->fail(FFD_ERR_STATE,
+                   "k_lstm_wave: unit %d waited longer than %d ms for the unit it depends on (the layer wavefront needs the "
+                   "device's compute units to itself: another stream or process was holding some); the results of that "
+                   "launch are invalid", code - 1, g_lstm_wave_spin_ms);
+}
+
 static int check_ready(ffd_ctx* ctx, int B) {
+  if (int rc = check_async(ctx)) return rc;
   if (!ctx->finalized) return ctx->fail(FFD_ERR_STATE, "weights not finalised (call ffd_finalize_weights)");
   if (B < 1) return ctx->fail(FFD_ERR_INVALID, "batch size %d", B);
   if ((double)B * ctx->desc.max_len * 4 * ctx->desc.d_model > 2.0e9)
@@ -1184,6 +1225,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
   const int d = m.d_model;
   hipStream_t s = (hipStream_t)stream;
   if (ctx->fresca_on && B > ctx->fwork_B) {
+    ctx->fwork_B = 0;
     if ((rc = dev_regrow(ctx, &ctx->score2, (size_t)B * m.max_len * m.n_channels))) return rc;
     if ((rc = dev_regrow(ctx, &ctx->fwork, (size_t)B * m.n_channels * (m.max_len / 2 + 1) + 4))) return rc;
     ctx->fwork_B = B;
@@ -1195,6 +1237,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
       ctx->temb_epoch != ctx->weight_epoch) {
     HIPCHECK(hipStreamSynchronize(s));
     if (n_steps > ctx->temb_cap) {
+      ctx->temb_cap = 0;
       if ((rc = dev_regrow(ctx, &ctx->temb_tab, (size_t)n_steps * d))) return rc;
       if ((rc = dev_regrow(ctx, &ctx->ts_dev, (size_t)n_steps))) return rc;
       ctx->temb_cap = n_steps;
@@ -1378,7 +1421,7 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
     case FFD_K_LSTM_REC:
       if (ls && lstm_wave_selected(B, m.d_model)) {  // every layer in one launch: x W_ih^T + h W_hh^T
         // per launch: batches past a 16-sample tile per CU go in sub-batches (exact where B is a multiple of that)
-        const double Ml = (double)(B < lstm_wave_max_batch() ? B : lstm_wave_max_batch()) * L;
+        const double Ml = (double)(B < lstm_wave_max_batch(L, m.d_model) ? B : lstm_wave_max_batch(L, m.d_model)) * L;
         name = "k_lstm_wave", fl = m.num_layers * 2.0 * Ml * 8.0 * d * d, by = m.num_layers * 4.0 * (2.0 * Ml * d + 8.0 * d * d);
       }
       else if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
@@ -1520,6 +1563,11 @@ int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_ou
   *ghz_out = ghz[ghz.size() / 2];
   if (loop_us_out) *loop_us_out = us[us.size() / 2];
   return FFD_OK;
+}
+
+int ffd_async_status(ffd_ctx* ctx) {
+  if (!ctx) return FFD_ERR_INVALID;
+  return check_async(ctx);
 }
 
 int ffd_probe_attn(ffd_ctx* ctx, int B, int n_recompute, double warm_seconds, int iters, float* ms_out,

@@ -210,12 +210,13 @@ extern int g_lstm_mfma_min_batch, g_lstm_mfma_s;
 hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
                             hipStream_t s);
 // batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
-// prog: >= 16 * ceil(B / 16) ints of device scratch (progress words, cleared by the launcher)
+// prog: >= 16 + 16 * ceil(B / 16) ints of device scratch (abort word + progress words, cleared by the launcher);
+// err: host-visible word that receives 1 + (unit index) when a wait on a progress word runs out of time
 bool lstm_wave_selected(int B, int D);
-int lstm_wave_max_batch();  // samples one k_lstm_wave launch takes (a 16-sample tile per CU); larger batches go in sub-batches
-extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk;
+int lstm_wave_max_batch(int L, int D);  // samples one k_lstm_wave launch takes (a 16-sample tile per CU, rows < 2^31 bytes); larger batches go in sub-batches
+extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk, g_lstm_wave_fault, g_lstm_wave_spin_ms;
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
-                            int B, int L, int D, int* prog, float* state, hipStream_t s);
+                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s);
 size_t lstm_wave_state_floats(int B, int D, int NL);
 
 hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,

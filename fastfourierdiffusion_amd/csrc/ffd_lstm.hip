@@ -433,10 +433,17 @@ struct LstmWaveArgs {
 // A unit depends on units of smaller index only ((k - 1, layer, tile) for the state, (k, layer - 1, tile) for the
 // rows, polled as they are produced), and a workgroup runs its units in index order: the unfinished unit of smallest
 // index is always running with its dependencies done, so the grid cannot deadlock (every spin is bounded anyway).
+// Every wait on a progress word is bounded in TIME (spin_ticks of the 100 MHz real-time counter).  A wait that runs out
+// is an ERROR, not a fall-through: the waiting wave writes a code to the host-visible word `err` (the library returns
+// FFD_ERR_STATE for it at its next entry point / ffd_async_status) and raises the launch's abort word, after which every
+// wait of every workgroup passes at once: the grid drains (on data that no longer means anything) instead of hanging.
+// The protocol needs the grid's P workgroups co-resident, i.e. the device's CUs to itself (include/ffd.h).
+// `fault` (tests, ffd_tune "lstm_wave_fault"): unit fault - 1 never publishes its progress.
 template <int D>
 __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, LstmWaveArgs wa, int n_layers, int n_tiles,
                                                       int T, int B, int L, int* __restrict__ prog,
-                                                      float* __restrict__ state) {
+                                                      float* __restrict__ state, int* __restrict__ err,
+                                                      int* __restrict__ abort_word, unsigned spin_ticks, int fault) {
   // Eight waves, two per SIMD, in two roles (the cell step of k_lstm_mfma split in two):
   //   waves 0-3 (recurrent): acc = gx_t image; acc += W_hh h_{t-1}^T (W_hh fragments in VGPRs); lane-local cell
   //                          update; h_t -> LDS.  Only this is on the recurrence's critical path.
@@ -497,6 +504,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   const int layer = rem / n_tiles, tile = rem - layer * n_tiles;  // (uniform)
   const int tb = kc * T, te = min(L, tb + T);                     // this unit's cell steps [tb, te); tb is even
   int* my_prog = prog + layer * n_tiles + tile;
+  const bool mute = fault > 0 && u == fault - 1;  // (tests) this unit withholds its progress
   const int* up_prog = layer > 0 ? prog + (layer - 1) * n_tiles + tile : nullptr;
   const unsigned st_base = (unsigned)((layer * n_tiles + tile) * SST * 4);  // byte offset of the state block
   load_weights(layer);
@@ -606,9 +614,25 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   // wave 4 waits until `word` has reached `need` (the other waves meet it at the next workgroup barrier)
   auto await_word = [&](const int* word, int& known, int need) {
     if (wave8 == 4 && known < need) {
-      for (int spin = 0; spin < (1 << 22); ++spin) {
+      const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+      for (unsigned spin = 0;; ++spin) {
         known = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (known >= need) break;
+        bool out = false;
+        if ((spin & 15) == 15) {  // the abort word (another wait has timed out) and the clock, every 16th poll
+          out = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+          if (!out && __builtin_amdgcn_s_memrealtime() - t_start > (unsigned long long)spin_ticks) {
+            out = true;
+            if (lane == 0) {
+              __hip_atomic_store(err, 1 + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // which unit gave up
+              __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        if (out) {
+          known = 1 << 30;  // this unit's later waits pass: the launch drains, the host reports the error
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
       }
     }
@@ -642,7 +666,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
     int mine = 0;
     await_word(my_prog, mine, tb);
   }
-  await_rows(min(tb + 3, te));
+  // rows tb .. tb+3 are requested before the loop's first barrier-protected wait: all four are awaited HERE, in front of
+  // barrier A (a wait inside the t == tb iteration would let waves 5-7 request row tb+3 before wave 4 has seen it
+  // published; with publications every CHP = 2 steps from an even tb this wait costs nothing extra)
+  await_rows(min(tb + 4, te));
   __syncthreads();  // A
   if (kc > 0) {  // h_{tb-1} -> h image 0 (tb is even)
 #pragma unroll
@@ -680,10 +707,8 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
       }
       await_rows(min(t + 4, te));
       __syncthreads();  // h_{t-1}, gx_t, x_{t+1} (ring slot s1) complete
-      if (publish && tg == 0) __hip_atomic_store(my_prog, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (publish && tg == 0 && !mute) __hip_atomic_store(my_prog, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       out_store(t - 1, cur, s2);  // x_{t-1} + h_{t-1}
-    } else {
-      await_rows(min(tb + 4, te));
     }
     if (t + 1 < te) input_part(s1, cur ^ 1);  // gx_{t+1}
     // slot s2 held x_{t-1}: its fragments were read two steps ago and this thread just wrote its rows back
@@ -705,7 +730,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tg == 0) __hip_atomic_store(my_prog, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tg == 0 && !mute) __hip_atomic_store(my_prog, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }  // units
 }
 
@@ -714,10 +739,17 @@ constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5
 int g_lstm_wave_persist = 1;  // 1: one launch, workgroups run their units in order (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
 int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
 int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
+int g_lstm_wave_fault = 0;    // tests: unit fault - 1 never publishes its progress (the waits on it must time out as an ERROR)
+int g_lstm_wave_spin_ms = 2000;  // time limit of one wait on a progress word (ffd_tune "lstm_wave_spin_ms")
 int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
 
 // (batches past a 16-sample tile per CU go through the launcher in sub-batches of 16 CUs samples)
-int lstm_wave_max_batch() { return 16 * num_cus(); }
+// ... and so that a sub-batch's rows stay inside one raw-buffer resource (< 2^31 bytes; long sequences)
+int lstm_wave_max_batch(int L, int D) {
+  const long long by_bytes = ((1ll << 31) - 1) / ((long long)L * D * 4) / 16 * 16;
+  const long long by_cus = 16ll * num_cus();
+  return (int)(by_bytes < by_cus ? by_bytes : by_cus);
+}
 bool lstm_wave_selected(int B, int D) {
   if (g_lstm_wave == 0 || D % 4 != 0 || D < 16) return false;
   return g_lstm_wave == 2 || !lstm_mfma_selected(B, D);
@@ -731,7 +763,10 @@ size_t lstm_wave_state_floats(int B, int D, int NL) {
 
 template <int D>
 static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const float* const* whh, const float* const* bsum,
-                                     int NL, int B, int L, int* prog, float* state, hipStream_t s) {
+                                     int NL, int B, int L, int* prog_all, float* state, int* err, hipStream_t s) {
+  int* abort_word = prog_all;  // word 0 of the buffer; the progress words start one 64-byte line further
+  int* prog = prog_all + 16;
+  const unsigned spin_ticks = (unsigned)g_lstm_wave_spin_ms * 100000u;  // 100 MHz ticks
   constexpr size_t lds = lstm_wave_lds(D);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_wave<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -751,10 +786,10 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
         const int n1 = nl - l1 < per ? nl - l1 : per;
         LstmWaveArgs wa{};
         for (int i = 0; i < n1; ++i) wa.wih[i] = wih[l0 + l1 + i], wa.whh[i] = whh[l0 + l1 + i], wa.bsum[i] = bsum[l0 + l1 + i];
-        hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)n1 * n_tiles, s);
+        hipError_t e = hipMemsetAsync(prog_all, 0, sizeof(int) * (16 + (size_t)n1 * n_tiles), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_lstm_wave<D>), dim3(n1 * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, Lfull, B, L, prog,
-                           (float*)nullptr);
+                           (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
@@ -784,10 +819,10 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
     const bool chunked = K > 1 && state != nullptr && Tc < L;
     LstmWaveArgs wa{};
     for (int i = 0; i < nl; ++i) wa.wih[i] = wih[l0 + i], wa.whh[i] = whh[l0 + i], wa.bsum[i] = bsum[l0 + i];
-    hipError_t e = hipMemsetAsync(prog, 0, sizeof(int) * (size_t)nl * n_tiles, s);
+    hipError_t e = hipMemsetAsync(prog_all, 0, sizeof(int) * (16 + (size_t)nl * n_tiles), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_lstm_wave<D>), dim3(P), dim3(512), lds, s, x, wa, nl, n_tiles, chunked ? Tc : Lfull, B, L, prog,
-                       chunked ? state : (float*)nullptr);
+                       chunked ? state : (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -795,12 +830,12 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
 }
 
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
-                            int B, int L, int D, int* prog, float* state, hipStream_t s) {
+                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s) {
   if (B <= 0 || NL <= 0) return hipSuccess;
-  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (size_t)B * L * D * 4 >= (1ull << 31)) return hipErrorInvalidValue;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (size_t)B * L * D * 4 >= (1ull << 31) || err == nullptr) return hipErrorInvalidValue;
   switch (D) {
 #define X(d) \
-  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, s);
+  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, err, s);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;

@@ -179,6 +179,8 @@ class DiffusionSampler:
                     global_step += num_diffusion_steps
                     model.cache.current_step = num_diffusion_steps - 1  # sampler.py:73-74 leaves step_idx
                 all_samples.append(X.cpu())
+                # (the copy has drained the stream) a kernel-side time-out of this batch's launches is an error here
+                N.check(ctx.lib.ffd_async_status(ctx.handle), ctx.handle, "sampling loop")
                 sample_cursor += batch_size
         return torch.cat(all_samples, dim=0)
 

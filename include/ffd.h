@@ -377,6 +377,17 @@ int ffd_bench_ffn(ffd_ctx* ctx, int B, int iters, float* ms_out, void* stream);
 int ffd_probe_ffn_clock(ffd_ctx* ctx, int B, double warm_seconds, double* ghz_out, double* loop_us_out,
                         unsigned long long* raw_out, int raw_capacity, int* nwg_out, void* stream);
 
+/* Status of the stream-ordered work this context has enqueued, for the one failure a kernel can only report after
+ * the fact: the LSTM backbone (LSTMScoreModule.forward, score_models.py:486-511) runs its layers as a wavefront of
+ * workgroups that wait on each other's progress words inside ONE launch (k_lstm_wave).  That protocol needs the
+ * launch's workgroups co-resident, i.e. THE DEVICE'S COMPUTE UNITS TO ITSELF: with another stream or process holding
+ * compute units a wait can outlast its time limit (2 s per wait; ffd_tune "lstm_wave_spin_ms").  Such a wait is an
+ * error, never a silent fall-through: the kernel records it, the launch drains, and the results of that launch are
+ * invalid.  Returns FFD_ERR_STATE (message via ffd_last_error) once for such a launch, FFD_OK otherwise; call it after
+ * synchronising the stream.  Every compute entry point makes the same check on entry, so the error also surfaces at
+ * the next call.  (The reference has no counterpart: its nn.LSTM layers are separate stream-ordered kernels.) */
+int ffd_async_status(ffd_ctx* ctx);
+
 /* Diagnostic + benchmark helper for the fused in-projection + attention launch of layer 0 (ffd_qkvattn.hip) at batch B
  * on random rows (replaces nothing in the reference: measurement scaffolding for cached_transformer.py:228-311's
  * kernel).  n_recompute < 0: plain layer; otherwise the E2-CRF mode of that recompute-set size (needs ffd_cache_enable

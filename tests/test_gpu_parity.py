@@ -8,6 +8,7 @@ Tolerances (fp32):
   trajectories     : <= 1e-5 x max-norm at up to 1000 steps with injected noise
 """
 import math
+import time
 
 import numpy as np
 import pytest
@@ -1601,3 +1602,97 @@ def test_f_sliced_ffn_forms_on_every_d_model(ffd, shape):
     for name, o in outs.items():
         assert rel_err(o, ref) < TOL_SCORE, name
         assert rel_err(o, outs["large"]) < 2e-6, name
+
+
+# ------------------------------------------------------------------ round 4 ----
+@pytest.mark.parametrize("c", cases.ROUND4_TRAJ_CASES, ids=lambda c: c["name"])
+def test_round4_traj_golden(ffd, golden, c):
+    """G13, pinned against the unmodified reference: BASELINE configs[3] at its full length (NASA charge, LSTM backbone,
+    1000 steps, on the production selection k_lstm_wave), the reference's class-default transformer (d_model 60,
+    score_models.py:31-33) at the ECG length with and without the cache, and a batch of the reference's default
+    sample_batch_size = 50 (cmd/conf/sampler/default.yaml:3) with the cache on."""
+    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
+
+    g = golden["g13_round4"]
+    m, sch = make_model(ffd, c)
+    B, L, C, N = c["B"], c["L"], c["C"], c["N"]
+    _pin_grid(sch, g[c["name"] + "_ts"], N)
+    sampler = DiffusionSampler(m, B, use_cache=c["use_cache"], cache_kwargs=dict(c.get("cache_kwargs", {})), z_chunk_steps=64)
+    sampler.inject_noise(synthetic.noise_stream((B, L, C), max(1, c["num_samples"] // B) * (N + 1), c["zseed"]))
+    out = sampler.sample(c["num_samples"], N)
+    assert tuple(out.shape) == g[c["name"]].shape
+    err = rel_err(out, g[c["name"]])
+    assert err < TOL_TRAJ, err
+
+
+@pytest.mark.parametrize("shared", [False, True], ids=["one_unit_per_workgroup", "time_shared_units"])
+def test_lstm_wavefront_timeout_is_an_error(ffd, shared):
+    """k_lstm_wave's waits on progress words are bounded in time, and a wait that runs out is an ERROR (never a
+    fall-through onto stale rows): with one unit's publications withheld (test knob) the launch must drain, the next
+    libffd call / ffd_async_status must fail with FFD_ERR_STATE, and the context must work again afterwards."""
+    from fastfourierdiffusion_amd import _native as N
+    from fastfourierdiffusion_amd._native import FFDError
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    B = 37
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4500 + B))).cuda()
+    good = m(batch_of(x, 0.45)).cpu()
+    ctx = m._ctx()
+    assert lib.ffd_async_status(ctx.handle) == 0
+    if shared:  # (tile, layer) pairs outnumber the workgroups: units of 16 cell steps, state handed over through memory
+        assert lib.ffd_tune(b"lstm_wave_per", 2) == 0 and lib.ffd_tune(b"lstm_wave_chunk", 16) == 0
+        assert torch.equal(m(batch_of(x, 0.45)).cpu(), good)
+    assert lib.ffd_tune(b"lstm_wave_spin_ms", 20) == 0 and lib.ffd_tune(b"lstm_wave_fault", 1) == 0
+    t0 = time.time()
+    bad = m(batch_of(x, 0.45))  # enqueued; unit 0 = (chunk 0, layer 0, tile 0) never publishes
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0, "the launch must drain after the first time-out"
+    del bad
+    assert lib.ffd_tune(b"lstm_wave_fault", 0) == 0
+    rc = lib.ffd_async_status(ctx.handle)
+    assert rc == -3, rc  # FFD_ERR_STATE
+    msg = lib.ffd_last_error(ctx.handle).decode()
+    assert "k_lstm_wave" in msg and "invalid" in msg, msg
+    assert lib.ffd_async_status(ctx.handle) == 0  # reported once
+    # the same failure surfaces at the next entry point when nobody asks
+    assert lib.ffd_tune(b"lstm_wave_fault", 1) == 0
+    m(batch_of(x, 0.45))
+    torch.cuda.synchronize()
+    assert lib.ffd_tune(b"lstm_wave_fault", 0) == 0
+    with pytest.raises(FFDError, match="k_lstm_wave"):
+        m(batch_of(x, 0.45))
+    # ... and the context is fine afterwards
+    assert torch.equal(m(batch_of(x, 0.45)).cpu(), good)
+    assert lib.ffd_async_status(ctx.handle) == 0
+
+
+def test_failed_workspace_growth_leaves_no_stale_capacity(ffd):
+    """A device allocation that fails while a workspace grows (injected: ffd_tune "fail_alloc_after") must come back as
+    FFD_ERR_NOMEM and leave the context usable: the capacity that guards the freed buffer reads 0, so the retry -- at
+    the same or a smaller batch -- allocates again instead of launching on a null / freed pointer."""
+    from fastfourierdiffusion_amd import _native as N
+    from fastfourierdiffusion_amd._native import FFDError
+
+    lib = N.lib()
+    for name in ("small", "small_lstm"):
+        c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+        m, _ = make_model(ffd, c)
+        x = torch.from_numpy(next(synthetic.noise_stream((40, c["L"], c["C"]), 1, 7100))).cuda()
+        small = m(batch_of(x[:3], 0.5)).cpu()
+        for nth in (1, 2, 3, 4):  # the n-th allocation of the growth to B = 40 fails
+            assert lib.ffd_tune(b"fail_alloc_after", nth) == 0
+            try:
+                out = m(batch_of(x, 0.5)).cpu()  # (fewer than nth allocations were needed: the call succeeds)
+            except FFDError as e:
+                assert "injected" in str(e), e
+                out = None
+            assert lib.ffd_tune(b"fail_alloc_after", 0) == 0
+            assert torch.equal(m(batch_of(x[:3], 0.5)).cpu(), small), (name, nth)
+            full = m(batch_of(x, 0.5)).cpu()
+            assert torch.isfinite(full).all() and rel_err(full[:3], small) < 2e-6, (name, nth)
+            if out is not None:
+                assert torch.equal(out, full)
+            m, _ = make_model(ffd, c)  # a fresh context for the next injection point
+            small = m(batch_of(x[:3], 0.5)).cpu()

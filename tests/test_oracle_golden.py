@@ -317,3 +317,19 @@ def test_round4_traj_golden(golden, c):
     ref = golden["g13_round4"][c["name"]]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
+
+
+def test_stock_module_form_equals_the_explicit_restatement(golden):
+    """bench.py's CPU baseline times the oracle with torch's stock nn.TransformerEncoder as backbone (the construction
+    of score_models.py:61-66, hence torch's fused encoder-layer path the reference runs on): it must be the same
+    function as the explicit restatement, and meet the same goldens."""
+    for name in ("ecg", "reftest"):
+        c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+        sd = make_sd(c)
+        B, L, C = c["B"], c["L"], c["C"]
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+        for tv in c["t_values"]:
+            t = torch.full((B,), tv, dtype=torch.float32)
+            a = O.score_forward_stock(x, t, sd, c["NL"], c["H"])
+            assert rel_err(a, O.score_forward(x, t, sd, c["NL"], c["H"])) < TOL_KERNEL
+            assert rel_err(a, golden["g5_models"][f"{name}_score_t{tv}"]) < TOL_KERNEL * 5

@@ -2,7 +2,7 @@
 through oracle/_ref_import.py, timed in its own harness regime (cmd/benchmark_cache.py:42-112: sample_batch_size 1,
 warm-up sample of 10 steps, then `num_samples` x `num_steps`, wall clock, cache off then cache on) next to the
 oracle's restatement of the same call sequence, plus a B = 32 score-step timing of both.  Result:
-profiles/r03_reference_cpu_timing.json -- the CPU ratio `speedup = t_no_cache / t_cache` (benchmark_cache.py:182)
+profiles/r04_reference_cpu_timing.json -- the CPU ratio `speedup = t_no_cache / t_cache` (benchmark_cache.py:182)
 that bench.py quotes as data in its `harness_b1` block.
 
     python tools/time_reference_cpu.py [--samples 10] [--steps 100] [--reps 3] [--threads N]
@@ -22,8 +22,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=10)
 ap.add_argument("--steps", type=int, default=100)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--only-b32", action="store_true", help="just the B = 32 step timings (seconds instead of minutes)")
 ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
-ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_reference_cpu_timing.json"))
+ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_reference_cpu_timing.json"))
 args = ap.parse_args()
 assert reference_available(), "the reference tree is only present in the build container"
 torch.set_num_threads(args.threads)
@@ -86,15 +87,19 @@ def step_time_b32(which):
     else:
         G = O.noise_scaling(L, True)
         ts, dt = O.timesteps(1000)
-        f = lambda x, tv: O.vp_step(x, O.score_forward(x, torch.full((B,), tv), sd, NL, H), torch.randn(B, L, C_, generator=g), tv, G, dt)
+        fwd = O.score_forward_stock if which == "oracle_stock" else O.score_forward
+        f = lambda x, tv: O.vp_step(x, fwd(x, torch.full((B,), tv), sd, NL, H), torch.randn(B, L, C_, generator=g), tv, G, dt)
     with torch.no_grad():
         for _ in range(2):
             f(x, 0.9)
-        t0 = time.time()
-        n = 10
-        for i in range(n):
-            x2 = f(x, 0.9 - 0.001 * i)
-        return (time.time() - t0) / n * 1e3
+        reps = []
+        for _ in range(3):
+            t0 = time.time()
+            n = 10
+            for i in range(n):
+                x2 = f(x, 0.9 - 0.001 * i)
+            reps.append((time.time() - t0) / n * 1e3)
+        return statistics.median(reps)
 
 
 res = {"what": "unmodified reference (imported via oracle/_ref_import.py) and the oracle restatement on this container's CPU",
@@ -102,7 +107,7 @@ res = {"what": "unmodified reference (imported via oracle/_ref_import.py) and th
        "threads": args.threads, "torch": torch.__version__, "num_samples": args.samples, "num_diffusion_steps": args.steps,
        "reps": args.reps, "harness_b1": {}}
 with torch.no_grad():
-    for name, fn in (("reference", ref_harness), ("oracle", oracle_harness)):
+    for name, fn in (() if args.only_b32 else (("reference", ref_harness), ("oracle", oracle_harness))):
         offs, ons = [], []
         for r in range(args.reps):
             offs.append(fn(False))
@@ -114,7 +119,11 @@ with torch.no_grad():
             "off_over_on_median": statistics.median(ratios),
             "ms_per_step_off_median": statistics.median(offs) / (args.samples * args.steps) * 1e3,
             "ms_per_step_on_median": statistics.median(ons) / (args.samples * args.steps) * 1e3}
-    res["step_b32_ms"] = {"reference": step_time_b32("reference"), "oracle": step_time_b32("oracle")}
+    res["step_b32_ms"] = {"reference": step_time_b32("reference"), "oracle": step_time_b32("oracle"),
+                          "oracle_stock": step_time_b32("oracle_stock")}
+    res["step_b32_ms"]["reference_again"] = step_time_b32("reference")
+    res["oracle_stock_over_reference_b32"] = res["step_b32_ms"]["oracle_stock"] / (
+        0.5 * (res["step_b32_ms"]["reference"] + res["step_b32_ms"]["reference_again"]))
     res["step_b32_samples_per_s_at_1000_steps"] = {k: 32.0 / v for k, v in res["step_b32_ms"].items()}
 print(json.dumps(res, indent=1))
 json.dump(res, open(args.out, "w"), indent=1)
