@@ -108,23 +108,25 @@ hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, i
   return hipGetLastError();
 }
 
-// Squared norms of the (scaled) q rows and of the k rows, maximum per 32-token tile: nrm[0 .. KT) keys, nrm[KT .. 2 KT)
-// queries.  |q . k| <= |q| |k| bounds every score of a (q-tile, key tile) pair; while that bound is within the
-// threshold T the online softmax needs no running maximum (its reference stays 0), and the block skips the max
-// reduction, the cross-half exchange and the refresh test -- about a tenth of its vector instructions.
+// Largest squared norm of the head's (scaled) q rows and of its k rows: nrm[0] keys, nrm[1] queries (as the bit patterns
+// of non-negative floats, which order like unsigned integers: one LDS atomic max per lane, no cross-lane reduction).
+// |q . k| <= |q| |k| bounds every score of the head; while that bound is within the threshold T the online softmax
+// needs no running maximum (its reference stays 0) and the key-tile loop skips the max reduction, the cross-half
+// exchange and the refresh test.  The caller zeroes nrm[0..1] before the barrier that precedes this call.
 template <int HD>
-__device__ __forceinline__ void tile_norms(const float* kts, const float* qts, float* nrm, int Lp, int KT, int tid, int nthreads) {
-  for (int j = tid; j < Lp; j += nthreads) {  // (tid and nthreads are multiples of 32 apart: a 32-lane group = one tile)
+__device__ __forceinline__ void head_norms(const float* kts, const float* qts, unsigned* nrm, int Lp, int LS, int tid, int nthreads) {
+  float km = 0.f, qm = 0.f;
+  for (int j = tid; j < Lp; j += nthreads) {
     float k2 = 0.f, q2 = 0.f;
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      const float kv = kts[e * Lp + j], qv = qts[e * Lp + j];
+      const float kv = kts[e * LS + j], qv = qts[e * LS + j];
       k2 = fmaf(kv, kv, k2), q2 = fmaf(qv, qv, q2);
     }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) k2 = fmaxf(k2, __shfl_xor(k2, o)), q2 = fmaxf(q2, __shfl_xor(q2, o));
-    if ((j & 31) == 0) nrm[j >> 5] = k2, nrm[KT + (j >> 5)] = q2;
+    km = fmaxf(km, k2), qm = fmaxf(qm, q2);
   }
+  atomicMax(nrm, __float_as_uint(km));
+  atomicMax(nrm + 1, __float_as_uint(qm));
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------
@@ -172,13 +174,18 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   }
   const int KT = (L + 31) >> 5;
   const int Lp = KT * 32;
+  // row stride of the LDS images: a compile-time 512 in the four-q-tiles-per-wave instance (launched for KT = 16 only), so
+  // that its LDS addresses are per-lane bases + immediate offsets; the run-time Lp elsewhere
+  const int LS = (QG == 4 && !SPLIT) ? 512 : Lp;
   float* vs = lds;                               // V   [Lp][8]
-  float* kts = vs + (size_t)Lp * 8;              // K^T [2*KST][Lp]
-  float* qts = kts + (size_t)2 * KST * Lp;       // Q^T [2*KST][Lp]   (already scaled by log2(e)/sqrt(hd))
+  float* kts = vs + (size_t)LS * 8;              // K^T [2*KST][LS]
+  float* qts = kts + (size_t)2 * KST * LS;       // Q^T [2*KST][LS]   (already scaled by log2(e)/sqrt(hd))
   const int half = lane >> 5, l31 = lane & 31;
+  unsigned* nrm = reinterpret_cast<unsigned*>(lds + (size_t)LS * (8 + 4 * KST) + (SPLIT ? 4 * 32 * (2 + 2 * HP) : 0));  // see head_norms
+  if (threadIdx.x < 2) nrm[threadIdx.x] = 0u;  // (ordered before head_norms by the barrier behind the projection)
 
   if constexpr (HD % 2 == 1) {  // odd head dims read one pad row / pad column: keep them zero
-    for (int idx = threadIdx.x; idx < Lp * (8 + 4 * KST); idx += blockDim.x) vs[idx] = 0.f;
+    for (int idx = threadIdx.x; idx < LS * (8 + 4 * KST); idx += blockDim.x) vs[idx] = 0.f;
     __syncthreads();
   }
 
@@ -193,14 +200,18 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int j = 0; j < S4; ++j) wf[ct][j] = Wq[((size_t)ct * S4 + j) * 64 + lane];
     const float* abp = awp + (size_t)H * NCT * S4 * 256 + (size_t)h * NCT * 16;
     float bias[NCT];
-    int kind[NCT], fe[NCT];  // 0 q, 1 k, 2 v, 3 none; feature's index inside its group
+    // where this lane's feature (16 ct + n) goes, worked out once: float index of token 0 in the LDS images -- Q^T / K^T
+    // rows take a lane's four tokens as one float4, V rows ([token][8]) as four scalars 8 floats apart; -1 = no feature
+    int sbase[NCT];
+    bool sv[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       bias[ct] = abp[ct * 16 + n];
       const int fi = 16 * ct + n;
-      const int reg = fi / HD;
-      kind[ct] = q_only ? (fi < HD ? 0 : 3) : (reg > 2 ? 3 : reg);
-      fe[ct] = fi - reg * HD;
+      const int reg = fi / HD, e = fi - reg * HD;
+      const int kind = q_only ? (fi < HD ? 0 : 3) : (reg > 2 ? 3 : reg);  // 0 q, 1 k, 2 v, 3 none
+      sv[ct] = kind == 2;
+      sbase[ct] = kind == 3 ? -1 : kind == 0 ? LS * 8 + 2 * KST * LS + e * LS : kind == 1 ? LS * 8 + e * LS : e;
     }
     const float* xb = x + (size_t)b * L * D;
     const int TT = Lp >> 4;  // every row of the LDS images gets a (finite) value
@@ -260,15 +271,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int ct = 0; ct < NCT; ++ct) {
         const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
                                 acc[ct][3] + bias[ct]};
-        if (kind[ct] == 0) {
-          *reinterpret_cast<float4*>(qts + (size_t)fe[ct] * Lp + t0) = o;
-        } else if (kind[ct] == 1) {
-          *reinterpret_cast<float4*>(kts + (size_t)fe[ct] * Lp + t0) = o;
-        } else if (kind[ct] == 2) {
-          vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
-          vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
-          vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
-          vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
+        if (sbase[ct] >= 0) {
+          if (!sv[ct]) {
+            *reinterpret_cast<float4*>(lds + sbase[ct] + t0) = o;
+          } else {
+            float* vp = lds + sbase[ct] + t0 * 8;
+            vp[0] = o.x, vp[8] = o.y, vp[16] = o.z, vp[24] = o.w;
+          }
         }
       }
     }
@@ -297,33 +306,35 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
         for (int e = 0; e < HD; ++e) kx[e] = kp[e], vx[e] = vp[e];
       }
 #pragma unroll
-      for (int e = 0; e < HD; ++e) kts[e * Lp + j] = kx[e];
+      for (int e = 0; e < HD; ++e) kts[e * LS + j] = kx[e];
       *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{vx[0], vx[1], vx[2], vx[3]};
       *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{vx[4], vx[5], vx[6], vx[7]};
     }
     if (q_only) {  // PURE: key rows in [L, Lp) were never written; they are masked but must be finite
       for (int j = L + threadIdx.x; j < Lp; j += blockDim.x) {
 #pragma unroll
-        for (int e = 0; e < HD; ++e) kts[e * Lp + j] = 0.f;
+        for (int e = 0; e < HD; ++e) kts[e * LS + j] = 0.f;
         *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
   __syncthreads();
-  float* nrm = lds + (size_t)Lp * (8 + 4 * KST) + (SPLIT ? 4 * 32 * (2 + 2 * HP) : 0);  // [2][KT], see tile_norms
-  tile_norms<HD>(kts, qts, nrm, Lp, KT, threadIdx.x, blockDim.x);
+  head_norms<HD>(kts, qts, nrm, Lp, LS, threadIdx.x, blockDim.x);
   // MIXED: batch element 0 publishes its recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
   if (kt_out != nullptr && b == 0 && qs == 0) {
     for (int idx = threadIdx.x; idx < n_own * HD; idx += blockDim.x) {
       const int j = idx / HD, e = idx - j * HD;
-      kt_out[(size_t)h * L * HD + idx] = kts[e * Lp + j];
+      kt_out[(size_t)h * L * HD + idx] = kts[e * LS + j];
       vt_out[(size_t)h * L * HD + idx] = vs[(size_t)j * 8 + e];
     }
   }
 
   __syncthreads();  // the tile norms
   if constexpr (STAMP) st_t[4] = FFD_STAMP_T();
+  // every score of this head is within +- sqrt(max |q|^2 max |k|^2) (wave-uniform)
+  const bool head_bounded =
+      __builtin_amdgcn_ballot_w64(__uint_as_float(nrm[1]) * __uint_as_float(nrm[0]) <= T * T) != 0;
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     if (q_first >= QT) t_hi = t_lo;  // ragged last workgroup: an empty piece
   }
   for (int qt0 = q_first; qt0 < q_end; qt0 += q_step) {
-    float qf[QG][KSX], mref[QG], qn2[QG];
+    float qf[QG][KSX], mref[QG];
     bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
     bool acc_empty[QG];
 #pragma unroll
@@ -361,10 +372,9 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
-        qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;  // dim HD starts at -m_ref = 0
+        qf[g][s] = (e < HD) ? qts[e * LS + 32 * qtile + l31] : 0.f;  // dim HD starts at -m_ref = 0
       }
       mref[g] = 0.f;
-      qn2[g] = nrm[KT + qtile];
       lsum[g] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
@@ -374,11 +384,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       unsigned long long st_a = 0;
       if constexpr (STAMP) st_a = FFD_STAMP_T();
       float kf[KSX];
-      const float kn2 = nrm[t];
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
-        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[(size_t)e * Lp + 32 * t + l31] : 0.f;
+        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[e * LS + 32 * t + l31] : 0.f;
       }
       if (xlane) kf[SX] = 1.0f;
       f32x16 sc[QG];
@@ -405,18 +414,21 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       }
       if (32 * t + 32 > L) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          if (32 * t + 8 * r4 + 8 > L) {  // (uniform) registers 4 r4 .. 4 r4 + 3 hold key rows 8 r4 .. 8 r4 + 7 of the tile
 #pragma unroll
-          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+            for (int rr = 0; rr < 4; ++rr) {
+              const bool dead = kbase + rr + 8 * r4 >= L;
+#pragma unroll
+              for (int g = 0; g < QG; ++g) sc[g][4 * r4 + rr] = dead ? -INFINITY : sc[g][4 * r4 + rr];
+            }
+          }
         }
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
-        // every score of this block is within +-sqrt(qn2 kn2): while that stays within T and no lane of the wave uses a
-        // reference, nothing below can trigger (wave-uniform: the norms are the same in every lane)
-        const bool bounded = !ref_on && qn2[g] * kn2 <= T * T;
-        if (__builtin_amdgcn_ballot_w64(!bounded) != 0) {
+        // while the head's bound stays within T and no lane of the wave uses a reference, nothing below can trigger
+        if (ref_on || !head_bounded) {
         float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     if constexpr (STAMP) st_t[5] = FFD_STAMP_T();
     if constexpr (SPLIT) {
       constexpr int PS = 2 + 2 * HP;  // per query row: reference exponent, row sum, unnormalised output
-      float* part = lds + (size_t)Lp * (8 + 4 * KST);  // [wave][32][PS]
+      float* part = lds + (size_t)LS * (8 + 4 * KST);  // [wave][32][PS]
       float l = lsum[0].x + lsum[0].y;
       l += __shfl_xor(l, 32);
       float o[2 * HP];
@@ -520,7 +532,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     for (int g = 0; g < QG; ++g) {
       float l = lsum[g].x + lsum[g].y;
       l += __shfl_xor(l, 32);
-      const float inv = 1.0f / l;
+      const float inv = __builtin_amdgcn_rcpf(l);  // (1 ulp; the IEEE division sequence is ten vector instructions per q-tile)
       const int q = 32 * (qt0 + g) + l31;
       float o[2 * HP];
 #pragma unroll
@@ -559,7 +571,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 // staged once in LDS and read as the MFMA B operand from there.  Two heads = 4 waves, one per SIMD: a 6-wave
 // workgroup (3 heads) leaves the CU with a single resident workgroup (two of its waves land on SIMDs 0 and 1,
 // so a second one never fits at 3 waves per SIMD) and was slower.
-template <int D, int HD, int HPW, int QG, int NCT, bool STAMP = false>
+template <int D, int HD, int HPW, int QG, int NCT, bool QO, bool STAMP = false>
 __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
@@ -600,10 +612,15 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   }
   const int KT = (L + 31) >> 5;
   const int Lp = KT * 32;
-  const int RS = Lp * (8 + 4 * KST);                           // floats per head region: V | K^T | Q^T
+  // the LDS images have a COMPILE-TIME row stride (a wave owns QG q-tiles, a head two waves: Lp <= LS): every LDS address
+  // below is one per-lane base + immediate offsets instead of multiplications by a run-time Lp
+  constexpr int LS = 64 * QG;
+  constexpr int RS = LS * (8 + 4 * KST);                       // floats per head region: V | K^T | Q^T
   float4* wl = reinterpret_cast<float4*>(lds + (size_t)HPW * RS);  // weight pack [NCT][S4][64] float4
   const int half = lane >> 5, l31 = lane & 31;
-  const int fph = q_only ? HD : 3 * HD;                        // features per head in this pack
+  constexpr int fph = QO ? HD : 3 * HD;                        // features per head in this pack (QO == q_only)
+  if (threadIdx.x < 2 * HPW)  // the heads' norm words (ordered before head_norms by the barriers of the projection)
+    reinterpret_cast<unsigned*>(lds + (size_t)HPW * RS + (size_t)NCT * S4 * 256)[threadIdx.x] = 0u;
 
   // ------------------------------------------------------------------ phase 1: projection
   {
@@ -640,16 +657,19 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     }
     const float* abp = awp + (size_t)NG * NCT * S4 * 256 + (size_t)hg * NCT * 16;
     float bias[NCTM];
-    int kind[NCTM], fe[NCTM], fh[NCTM];  // 0 q, 1 k, 2 v, 3 none; index inside its group; head inside the workgroup
+    // where this lane's feature (16 ct + n) goes, worked out once: float index of token 0 in the LDS images -- Q^T / K^T
+    // rows take a lane's four tokens as one float4, V rows ([token][8]) as four scalars 8 floats apart; -1 = no feature
+    int sbase[NCTM];
+    bool sv[NCTM];
 #pragma unroll
     for (int ct = 0; ct < NCTM; ++ct) {
       bias[ct] = abp[ct * 16 + n];
       const int fi = 16 * ct + n;
       const int hh = fi / fph, f = fi - hh * fph;
-      const int reg = f / HD;
-      fh[ct] = hh < HPW ? hh : 0;
-      kind[ct] = hh >= HPW ? 3 : reg;
-      fe[ct] = f - reg * HD;
+      const int reg = f / HD, e = f - reg * HD;
+      sv[ct] = reg == 2;
+      sbase[ct] = hh >= HPW ? -1
+                  : hh * RS + (reg == 0 ? LS * 8 + 2 * KST * LS + e * LS : reg == 1 ? LS * 8 + e * LS : e);
     }
     __syncthreads();
     if constexpr (STAMP) st_t[2] = FFD_STAMP_T();
@@ -685,20 +705,15 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
 #pragma unroll
       for (int ct = 0; ct < NCTM; ++ct) {
-        float* reg_vs = lds + (size_t)fh[ct] * RS;
-        float* reg_kts = reg_vs + (size_t)Lp * 8;
-        float* reg_qts = reg_kts + (size_t)2 * KST * Lp;
         const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
                                 acc[ct][3] + bias[ct]};
-        if (kind[ct] == 0) {
-          *reinterpret_cast<float4*>(reg_qts + (size_t)fe[ct] * Lp + t0) = o;
-        } else if (kind[ct] == 1) {
-          *reinterpret_cast<float4*>(reg_kts + (size_t)fe[ct] * Lp + t0) = o;
-        } else if (kind[ct] == 2) {
-          reg_vs[(size_t)(t0 + 0) * 8 + fe[ct]] = o.x;
-          reg_vs[(size_t)(t0 + 1) * 8 + fe[ct]] = o.y;
-          reg_vs[(size_t)(t0 + 2) * 8 + fe[ct]] = o.z;
-          reg_vs[(size_t)(t0 + 3) * 8 + fe[ct]] = o.w;
+        if (sbase[ct] >= 0) {
+          if (!sv[ct]) {
+            *reinterpret_cast<float4*>(lds + sbase[ct] + t0) = o;
+          } else {
+            float* vp = lds + sbase[ct] + t0 * 8;
+            vp[0] = o.x, vp[8] = o.y, vp[16] = o.z, vp[24] = o.w;
+          }
         }
       }
     }
@@ -742,8 +757,8 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   const int hh = wave >> 1, gw = wave & 1;
   const int h = hg * HPW + hh;
   float* vs = lds + (size_t)hh * RS;
-  float* kts = vs + (size_t)Lp * 8;
-  float* qts = kts + (size_t)2 * KST * Lp;
+  float* kts = vs + LS * 8;
+  float* qts = kts + 2 * KST * LS;
   // rows served by the shared tables (PURE: all of them; MIXED: tokens >= n_own): the head's two waves fill them
   if (kt != nullptr) {
     if (!q_only && n_own > 0) __syncthreads();  // MIXED: the projection wrote these rows first
@@ -768,33 +783,36 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
         for (int e = 0; e < HD; ++e) kx[e] = kp[e], vx[e] = vp[e];
       }
 #pragma unroll
-      for (int e = 0; e < HD; ++e) kts[e * Lp + j] = kx[e];
+      for (int e = 0; e < HD; ++e) kts[e * LS + j] = kx[e];
       *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{vx[0], vx[1], vx[2], vx[3]};
       *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{vx[4], vx[5], vx[6], vx[7]};
     }
     if (q_only) {  // PURE: key rows in [L, Lp) were never written; they are masked but must be finite
       for (int j = L + tid2; j < Lp; j += 128) {
 #pragma unroll
-        for (int e = 0; e < HD; ++e) kts[e * Lp + j] = 0.f;
+        for (int e = 0; e < HD; ++e) kts[e * LS + j] = 0.f;
         *reinterpret_cast<float4*>(vs + (size_t)j * 8) = float4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<float4*>(vs + (size_t)j * 8 + 4) = float4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
   __syncthreads();
-  float* nrm = lds + (size_t)HPW * RS + (size_t)NCT * S4 * 256 + (size_t)hh * 2 * KT;  // this head's [2][KT], see tile_norms
-  tile_norms<HD>(kts, qts, nrm, Lp, KT, gw * 64 + lane, 128);
+  unsigned* nrm = reinterpret_cast<unsigned*>(lds + (size_t)HPW * RS + (size_t)NCT * S4 * 256) + 2 * hh;  // this head's pair, see head_norms
+  head_norms<HD>(kts, qts, nrm, Lp, LS, gw * 64 + lane, 128);
   if (kt_out != nullptr && b == 0) {  // MIXED: batch element 0 publishes its recomputed rows
     const int tid2 = gw * 64 + lane;
     for (int idx = tid2; idx < n_own * HD; idx += 128) {
       const int j = idx / HD, e = idx - j * HD;
-      kt_out[(size_t)h * L * HD + idx] = kts[e * Lp + j];
+      kt_out[(size_t)h * L * HD + idx] = kts[e * LS + j];
       vt_out[(size_t)h * L * HD + idx] = vs[(size_t)j * 8 + e];
     }
   }
 
   __syncthreads();  // the tile norms
   if constexpr (STAMP) st_t[4] = FFD_STAMP_T();
+  // every score of this head is within +- sqrt(max |q|^2 max |k|^2) (wave-uniform)
+  const bool head_bounded =
+      __builtin_amdgcn_ballot_w64(__uint_as_float(nrm[1]) * __uint_as_float(nrm[0]) <= T * T) != 0;
   // ------------------------------------------------------------------ phase 2: attention (see k_attention_pk)
   const bool xlane = half == HX;
   constexpr int PF = 4;
@@ -811,7 +829,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   };
   const int QT = KT;
   for (int qt0 = gw * QG; qt0 < QT; qt0 += 2 * QG) {
-    float qf[QG][KSX], mref[QG], qn2[QG];
+    float qf[QG][KSX], mref[QG];
     bool ref_on = false;  // wave-uniform: some lane of this wave carries a non-zero reference
     bool acc_empty[QG];
 #pragma unroll
@@ -823,10 +841,9 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
-        qf[g][s] = (e < HD) ? qts[(size_t)e * Lp + 32 * qtile + l31] : 0.f;
+        qf[g][s] = (e < HD) ? qts[e * LS + 32 * qtile + l31] : 0.f;
       }
       mref[g] = 0.f;
-      qn2[g] = nrm[KT + qtile];
       lsum[g] = f32x2{0.f, 0.f};
 #pragma unroll
       for (int e = 0; e < HP; ++e) acc[g][e] = f32x2{0.f, 0.f};
@@ -836,11 +853,10 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       unsigned long long st_a = 0;
       if constexpr (STAMP) st_a = FFD_STAMP_T();
       float kf[KSX];
-      const float kn2 = nrm[t];
 #pragma unroll
       for (int s = 0; s < KSX; ++s) {
         const int e = 2 * s + half;
-        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[(size_t)e * Lp + 32 * t + l31] : 0.f;
+        kf[s] = (s < KST && (2 * s + 1 < HD || half == 0)) ? kts[e * LS + 32 * t + l31] : 0.f;
       }
       if (xlane) kf[SX] = 1.0f;
       f32x16 sc[QG];
@@ -867,18 +883,21 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
       }
       if (32 * t + 32 > L) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const bool dead = kbase + (r & 3) + 8 * (r >> 2) >= L;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          if (32 * t + 8 * r4 + 8 > L) {  // (uniform) registers 4 r4 .. 4 r4 + 3 hold key rows 8 r4 .. 8 r4 + 7 of the tile
 #pragma unroll
-          for (int g = 0; g < QG; ++g) sc[g][r] = dead ? -INFINITY : sc[g][r];
+            for (int rr = 0; rr < 4; ++rr) {
+              const bool dead = kbase + rr + 8 * r4 >= L;
+#pragma unroll
+              for (int g = 0; g < QG; ++g) sc[g][4 * r4 + rr] = dead ? -INFINITY : sc[g][4 * r4 + rr];
+            }
+          }
         }
       }
 #pragma unroll
       for (int g = 0; g < QG; ++g) {
-        // every score of this block is within +-sqrt(qn2 kn2): while that stays within T and no lane of the wave uses a
-        // reference, nothing below can trigger (wave-uniform: the norms are the same in every lane)
-        const bool bounded = !ref_on && qn2[g] * kn2 <= T * T;
-        if (__builtin_amdgcn_ballot_w64(!bounded) != 0) {
+        // while the head's bound stays within T and no lane of the wave uses a reference, nothing below can trigger
+        if (ref_on || !head_bounded) {
         float bm = __builtin_fmaxf(__builtin_fmaxf(sc[g][0], sc[g][1]), sc[g][2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) bm = __builtin_fmaxf(__builtin_fmaxf(bm, sc[g][r]), sc[g][r + 1]);
@@ -946,7 +965,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     for (int g = 0; g < QG; ++g) {
       float l = lsum[g].x + lsum[g].y;
       l += __shfl_xor(l, 32);
-      const float inv = 1.0f / l;
+      const float inv = __builtin_amdgcn_rcpf(l);  // (1 ulp; the IEEE division sequence is ten vector instructions per q-tile)
       const int q = 32 * (qt0 + g) + l31;
       float o[2 * HP];
 #pragma unroll
@@ -975,24 +994,25 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   }
 }
 
-template <int D, int HD, int HPW, int QG, int NCT>
+template <int D, int HD, int HPW, int QG, int NCT, bool QO>
 static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
                               float* vt_out, float* out, int B, int L, int n_own, int q_only, hipStream_t s,
                               unsigned long long* stamp) {
   constexpr int KST = (HD + 1) / 2;
   constexpr int S4 = (D + 15) / 16;
   const int KT = (L + 31) / 32;
-  const size_t lds = ((size_t)HPW * KT * 32 * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2 * KT) * sizeof(float);
+  const size_t lds = ((size_t)HPW * 64 * QG * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2) * sizeof(float);
   if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
   if constexpr (D == 72 && HD == 6) {  // (the stamped twin exists for the headline shape only)
     if (stamp != nullptr) {
-      hipLaunchKernelGGL((k_qkv_attention_mh<D, HD, HPW, QG, NCT, true>), dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds,
+      hipLaunchKernelGGL((k_qkv_attention_mh<D, HD, HPW, QG, NCT, QO, true>), dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds,
                          s, x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, q_only, stamp);
       return hipGetLastError();
     }
   }
   if (stamp != nullptr) return hipErrorInvalidValue;
-  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT>;
+  if (q_only != (QO ? 1 : 0)) return hipErrorInvalidValue;
+  auto kern = k_qkv_attention_mh<D, HD, HPW, QG, NCT, QO>;
   hipLaunchKernelGGL(kern, dim3(B * (D / HD / HPW)), dim3(128 * HPW), lds, s, x, awp, kt, vt, kt_out, vt_out, out, B, L,
                      n_own, q_only, (unsigned long long*)nullptr);
   return hipGetLastError();
@@ -1007,8 +1027,8 @@ static hipError_t launch_mh2(const float* x, const float* awp, int q_only, const
   const int QG = cdiv((L + 31) / 32, 2);
 #define FFD_MH(qg)                                                                                                   \
   if (QG == qg)                                                                                                      \
-    return q_only ? launch_mh_t<D, HD, 2, qg, NQ>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s, stamp)     \
-                  : launch_mh_t<D, HD, 2, qg, NF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
+    return q_only ? launch_mh_t<D, HD, 2, qg, NQ, true>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s, stamp)     \
+                  : launch_mh_t<D, HD, 2, qg, NF, false>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
   FFD_MH(1) FFD_MH(2) FFD_MH(3)
 #undef FFD_MH
   return hipErrorInvalidValue;
