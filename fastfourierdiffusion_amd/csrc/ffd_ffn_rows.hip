@@ -279,7 +279,9 @@ __device__ __forceinline__ void raw_rows(const f32x16* acc, const f32x4* rem, co
 // SL (sliced form, mid-size M; with OP only): workgroup u takes tile u / nslice and the hidden units of slice u % nslice
 // only (its share of the chunk slots, after the out-projection slot every slice recomputes), and stores its partial rows
 // raw -- slice 0 with x1 + b2 added -- to Y[slice][M][D]; k_rows_reduce_ln adds the slices in order and normalises.
-// One unit per workgroup (the grid is tiles x nslice <= the CUs).
+// The grid is g x nslice workgroups (<= the CUs): workgroup (t0, slice) takes tiles t0, t0 + g, ... of its slice (round 4:
+// where tiles x nslice exceeds the CUs the units go through them in rounds, e.g. ECG B = 384: 187 tiles x 4 slices on
+// 64 x 4 workgroups in 3 rounds of a quarter tile instead of one round that leaves 69 CUs idle).
 // ONE: at most one tile per workgroup (the grid covers the tiles: ECG B = 512 is 250 tiles of 384 rows): the tile loop
 // is gone at compile time, and with it the loop-carried row registers that cost the fused form 68 B of scratch.
 template <int D, int NW, int CPS, int NSLOT, int PR, bool OP, bool SL, bool ONE>
@@ -320,7 +322,10 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   const int slot_first = SL ? slice * (F / (32 * CPS)) / nslice : 0;
   const int nchunk_slots = SL ? (slice + 1) * (F / (32 * CPS)) / nslice - slot_first : F / (32 * CPS);
   const int NSL = nchunk_slots + (OP ? 1 : 0);  // slots per tile (fused form: slot 0 = the out-projection)
-  const int my_tiles = SL ? ((int)blockIdx.x / nslice < ntiles ? 1 : 0)
+  // (sliced form: the grid is g tiles x nslice workgroups; workgroup (t0, slice) walks tiles t0, t0 + g, ... of ITS slice,
+  //  so the ring's slot stream is the same for every tile it takes)
+  const int tstride = SL ? (int)gridDim.x / nslice : (int)gridDim.x;
+  const int my_tiles = SL ? ((int)blockIdx.x / nslice < ntiles ? (ntiles - 1 - (int)blockIdx.x / nslice) / tstride + 1 : 0)
                        : ONE ? ((int)blockIdx.x < ntiles ? 1 : 0)
                              : ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
   const int total = my_tiles * NSL;
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
       if (st_tiles == 0) st_epi = __builtin_amdgcn_s_memrealtime();
       ++st_tiles;
     }
-    tile += gridDim.x;
+    tile += tstride;
     if (tl + 1 < my_tiles) {  // the next tile's rows (the first tile's came with the ring fill)
       load_rows(X, xv, xrem);
       if (OP) load_rows(Rin, rin, rinrem);
@@ -715,10 +720,14 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
     if (g_ffn_rows_nw && g_ffn_rows_nw != nw) continue;
     const int tiles = cdiv(M, 32 * nw);
     const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots, p_us = nw == 12 ? 10.0 : 7.0;
-    const int smax = num_cus() / tiles < nslots ? num_cus() / tiles : nslots;
+    const int smax = nslots < 16 ? nslots : 16;
     for (int sl = 2; sl <= smax; ++sl) {
       if (g_rows_slices > 0 && g_rows_slices != sl) continue;
-      const double t = p_us + cdiv(nslots, sl) * slot_us + 15.0 + 6.0 + 1.2e-4 * M * (sl + 1) * D * 4 / 1000.0;
+      // g tiles in flight, the tiles x sl units in `rounds` rounds of (out-projection slot + the slice's chunk slots)
+      const int g = num_cus() / sl < tiles ? num_cus() / sl : tiles;
+      if (g < 1) continue;
+      const int rounds = cdiv(tiles, g);
+      const double t = rounds * (p_us + cdiv(nslots, sl) * slot_us) + 15.0 + 6.0 + 1.2e-4 * M * (sl + 1) * D * 4 / 1000.0;
       if (t < best) best = t, bnw = nw, bs = sl;
     }
   }
@@ -759,7 +768,8 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
   constexpr int per_cu_lds = (160 * 1024) / (FfnRowsCfg<D, NW, CPS, NSLOT>::LDS_FLOATS * 4);
   constexpr int per_cu = per_cu_lds < 12 / NW ? per_cu_lds : 12 / NW;
   const int slots = per_cu * num_cus();
-  const int grid = a.nslice > 0 ? ntiles * a.nslice : ntiles < slots ? ntiles : slots;
+  const int gsl = a.nslice > 0 ? (slots / a.nslice < ntiles ? slots / a.nslice : ntiles) : 0;  // tiles in flight, sliced form
+  const int grid = a.nslice > 0 ? gsl * a.nslice : ntiles < slots ? ntiles : slots;
   const LayerWeights& w = *a.w;
   constexpr int PRV = NW > 4 ? 1 : 0;  // descending wave priority through a barrier interval: with > 1 wave per SIMD
 #define FFD_ROWS_LAUNCH2(PR, OP, SL, ONE)                                                                              \
@@ -777,7 +787,7 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
     if (a.fused) {
       if constexpr (NW >= 8) {
         if (a.nslice > 0) {
-          if (a.nslice * ntiles > slots || a.nslice > a.F / 64) return hipErrorInvalidValue;
+          if (gsl < 1 || a.nslice > a.F / 64) return hipErrorInvalidValue;
           FFD_ROWS_LAUNCH(PRV, true, true);
           return hipGetLastError();
         }

@@ -1395,6 +1395,38 @@ def test_rows_sliced_form_agrees_with_the_other_forms(ffd, name, batches):
         assert rel_err(auto.cpu(), ref.cpu()) < 2e-6, B
 
 
+def test_rows_sliced_form_in_rounds(ffd):
+    """Round 4: where tiles x slices exceeds the CUs (ECG B = 384: 187 tiles x 4 slices) the sliced form's workgroups walk
+    several tiles of their slice: bit-identical with the one-round result of the same slicing wherever both exist (a
+    smaller batch whose units fit the chip), equal to the unsliced form to rounding, independent of the batch around a
+    sample, and the default plan at B = 384 / 768 is such a multi-round slicing."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "ecg")
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((768, c["L"], c["C"]), 1, 777))).cuda()
+    for B, nw, S in ((384, 12, 4), (384, 8, 3), (768, 12, 2), (500, 12, 5)):
+        xb = x[:B].contiguous()
+        assert lib.ffd_tune(b"rows_slices", -1) == 0
+        ref = m(batch_of(xb, 0.4))
+        assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"rows_slices", S) == 0
+        assert -(-B * c["L"] // (32 * nw)) * S > 256  # more units than CUs: rounds
+        a = m(batch_of(xb, 0.4))
+        assert torch.equal(a, m(batch_of(xb, 0.4))), (B, nw, S)
+        assert rel_err(a.cpu(), ref.cpu()) < 2e-6, (B, nw, S)
+        nfit = (256 // S) * 32 * nw // c["L"]  # samples whose tiles x S units fit the chip in one round
+        one_round = m(batch_of(xb[:nfit].contiguous(), 0.4))
+        assert torch.equal(one_round, a[:nfit]), (B, nw, S)  # same slicing, same summation order: the same bits
+        assert lib.ffd_tune(b"reset", 0) == 0
+    for B in (384, 768):
+        xb = x[:B].contiguous()
+        auto = m(batch_of(xb, 0.4))
+        assert lib.ffd_tune(b"rows_slices", -1) == 0
+        assert rel_err(auto.cpu(), m(batch_of(xb, 0.4)).cpu()) < 2e-6, B
+        assert lib.ffd_tune(b"reset", 0) == 0
+
+
 def test_ffn_ln_persistent_grid_equals_one_workgroup_per_tile(ffd):
     """k_ffn_ln (the F-split workgroup; large M of every d_model without a k_ffn_rows instance, selected here with
     ffd_tune "ffn_rows" = 0) walks its tiles with a persistent grid: bit-identical with one workgroup per tile and with
