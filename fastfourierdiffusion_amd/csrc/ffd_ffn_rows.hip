@@ -38,8 +38,13 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 //                       two lane halves of register s of a 32x32 accumulator tile that holds the row (ring_kperm), so
 //                       that X rows loaded (or computed) in accumulator layout ARE the B operands, no lane movement
 //   4 CT groups         item idx: r = idx / CT, ct = idx % CT:   W2[32 ct + (lane & 31)][32 p + f_r + 4 (lane >> 5)]
-//   4 NG groups         (4x4x1 A operands) item idx: r = idx / NG, g = idx % NG:
+//   4 NG LOGICAL groups (4x4x1 A operands) item idx: r = idx / NG, g = idx % NG:
 //                                                        W2[32 CT + 4 g + (lane & 3)][32 p + f_r + 4 (lane >> 5)]
+//                       -- a lane's operand depends on (lane & 3, lane >> 5) only: 8 distinct float4 per group.  Round 4:
+//                       stored COMPACTED, eight logical groups per 1 KiB piece ([logical group % 8][lane class = (lane & 3)
+//                       + 4 (lane >> 5)][4]), read with a broadcast ds_read_b128: the remainder columns cost an eighth
+//                       of the ring bytes and DMA pieces they used to (d_model 72: 19 pieces per chunk instead of 26;
+//                       d_model 60, with 7 remainder groups: 17 instead of 41, which is what lets it fit the LDS)
 //   last group          lanes 0..7: b1[32 p + 4 lane + j]
 constexpr __host__ __device__ int ring_ct(int D) { return D / 32; }
 constexpr __host__ __device__ int ring_ng(int D) { return (D % 32) / 4; }
@@ -50,7 +55,16 @@ constexpr __host__ __device__ int ring_kperm(int D, int s, int half) {
   return s < 16 * ring_ct(D) ? 32 * (s / 16) + 8 * ((s % 16) / 4) + 4 * half + s % 4
                              : 32 * ring_ct(D) + 4 * (2 * ((s - 16 * ring_ct(D)) / 4) + half) + (s - 16 * ring_ct(D)) % 4;
 }
-constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nq1(D) + 4 * (ring_ct(D) + ring_ng(D)) + 1; }
+constexpr __host__ __device__ int ring_nmain(int D) { return ring_nq1(D) + 4 * ring_ct(D); }   // full 1 KiB groups of a chunk
+constexpr __host__ __device__ int ring_nrem(int D) { return 4 * ring_ng(D); }                    // logical remainder groups
+constexpr __host__ __device__ int ring_nfc(int D) { return ring_nmain(D) + ring_nrem(D); }       // logical fragment groups of a chunk
+constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nmain(D) + cdiv(ring_nrem(D), 8) + 1; }  // 1 KiB pieces
+// float offset (inside its chunk / slot) of what `lane` reads of logical group k, k < nmain full groups, then compacted ones
+constexpr __host__ __device__ int ring_frag_off(int nmain, int k, int lane) {
+  return k < nmain ? k * 256 + lane * 4
+                   : (nmain + (k - nmain) / 8) * 256 + (((k - nmain) % 8) * 8 + (lane & 3) + 4 * (lane >> 5)) * 4;
+}
+#ifndef FFD_ROWS_EXTRA_D  // (the pack kernels, knobs, planner and entry points live in the d_model 72 translation unit only)
 size_t ffn_ring_floats(int D, int F) { return (size_t)(F / 32) * ring_chunk_groups(D) * 256; }
 
 __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __restrict__ b1,
@@ -69,9 +83,12 @@ __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __res
     } else if (g < NQ1 + 4 * CT) {
       const int idx = 4 * (g - NQ1) + j, r = idx / CT, ct = idx % CT;
       v = W2[(size_t)(32 * ct + (lane & 31)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
-    } else if (g < SG - 1) {
-      const int idx = 4 * (g - NQ1 - 4 * CT) + j, r = idx / NG, gq = idx % NG;
-      v = W2[(size_t)(32 * CT + 4 * gq + (lane & 3)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
+    } else if (g < SG - 1) {  // compacted remainder piece: [logical group % 8][lane class][4]
+      const int t = (int)(o & 255), lc = (t >> 2) & 7, kr = (g - NQ1 - 4 * CT) * 8 + (t >> 5);
+      if (kr < 4 * NG) {
+        const int idx = 4 * kr + j, r = idx / NG, gq = idx % NG;
+        v = W2[(size_t)(32 * CT + 4 * gq + (lc & 3)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * (lc >> 2)];
+      }
     } else if (lane < 8) {
       v = b1[32 * p + 4 * lane + j];
     }
@@ -79,12 +96,15 @@ __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __res
   }
 }
 
+#endif
 // ---- out-projection slot (fused out-proj + LN1 form): [NPM main-tile groups][NPR remainder groups][64 lanes][4] --------
 //   main groups      item idx = 4 g + j: k-step s = idx / CT, column tile ct = idx % CT:  Wo[32 ct + (lane & 31)][kperm(s, lane >> 5)]
 //   remainder groups item idx: s = idx / NG, gq = idx % NG (4x4x1 A operands):   Wo[32 CT + 4 gq + (lane & 3)][kperm(s, lane >> 5)]
+//                    (logical groups, stored compacted eight to a piece like the ring's remainder groups)
 // (the attention rows, loaded in accumulator layout like the FFN's X rows, are the B operands under the same k permutation)
 constexpr __host__ __device__ int oproj_npm(int D) { return cdiv(ring_ks2(D) * ring_ct(D), 4); }
 constexpr __host__ __device__ int oproj_npr(int D) { return cdiv(ring_ks2(D) * ring_ng(D), 4); }
+#ifndef FFD_ROWS_EXTRA_D
 size_t ffn_ring_oproj_floats(int D) { return (size_t)2 * ring_chunk_groups(D) * 256; }  // one two-chunk slot
 
 __global__ void k_pack_oproj_ring(const float* __restrict__ Wo, float* __restrict__ out, int D) {
@@ -99,11 +119,14 @@ __global__ void k_pack_oproj_ring(const float* __restrict__ Wo, float* __restric
         const int kcol = ring_kperm(D, s, half);
         if (kcol < D) v = Wo[(size_t)(32 * ct + (lane & 31)) * D + kcol];
       }
-    } else if (g < NPM + NPR) {
-      const int idx = 4 * (g - NPM) + j, s = idx / NG, gq = idx % NG;
-      if (s < KS2) {
-        const int kcol = ring_kperm(D, s, half);
-        if (kcol < D) v = Wo[(size_t)(32 * CT + 4 * gq + (lane & 3)) * D + kcol];
+    } else if (g < NPM + (NPR + 7) / 8) {  // compacted remainder piece: [logical group % 8][lane class][4]
+      const int t = o & 255, lc = (t >> 2) & 7, kr = (g - NPM) * 8 + (t >> 5);
+      if (kr < NPR) {
+        const int idx = 4 * kr + j, s = idx / NG, gq = idx % NG;
+        if (s < KS2) {
+          const int kcol = ring_kperm(D, s, lc >> 2);
+          if (kcol < D) v = Wo[(size_t)(32 * CT + 4 * gq + (lc & 3)) * D + kcol];
+        }
       }
     }
     out[o] = v;
@@ -111,7 +134,7 @@ __global__ void k_pack_oproj_ring(const float* __restrict__ Wo, float* __restric
 }
 
 hipError_t launch_pack_oproj_ring(const float* Wo, float* out, int D, hipStream_t s) {
-  if (D % 8 != 0 || D < 32) return hipErrorInvalidValue;
+  if (D % 4 != 0 || D < 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k_pack_oproj_ring, dim3(64), dim3(256), 0, s, Wo, out, D);
   return hipGetLastError();
 }
@@ -123,14 +146,17 @@ hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W
   return hipGetLastError();
 }
 
+#endif
+
 __device__ __forceinline__ float f4e(const float4& q, int j) { return j == 0 ? q.x : j == 1 ? q.y : j == 2 ? q.z : q.w; }
 
 template <int D, int NW, int CPS, int NSLOT>
 struct FfnRowsCfg {
   static constexpr int KS2 = ring_ks2(D);
   static constexpr int CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D);
-  static constexpr int SGC = ring_chunk_groups(D);           // 1 KiB groups per chunk (the last one: bias)
-  static constexpr int NFC = SGC - 1;                        // fragment groups of a chunk
+  static constexpr int SGC = ring_chunk_groups(D);           // 1 KiB pieces per chunk (the last one: bias)
+  static constexpr int NMAIN = ring_nmain(D);                // full groups of a chunk; the remainder groups after them are compacted
+  static constexpr int NFC = ring_nfc(D);                    // (logical) fragment groups of a chunk = ds_read_b128 per lane
   static constexpr int SLOT_G = CPS * SGC;
   static constexpr int SLOT_FLOATS = SLOT_G * 256;
   static constexpr int LNP = 6 * D;                          // b2, gamma2, beta2; out-proj bias, gamma1, beta1 (fused form)
@@ -142,10 +168,11 @@ struct FfnRowsCfg {
   static constexpr int NPW = cdiv(SLOT_G, NW);               // DMA pieces of a slot per wave (the same for every wave: the
                                                              // last pieces of a slot are fetched twice when NW does not divide)
   static_assert((AHEAD - 2) * NPW + NST <= 63 && AHEAD >= 2, "vmcnt range");
-  static_assert(NPW <= NFC - NQ1, "one DMA piece per fragment group after the barrier");
+  static_assert(NPW <= 2 * (NFC - NQ1), "at most two DMA pieces per fragment group after the barrier");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
   // fused out-projection slot
-  static constexpr int NPM = oproj_npm(D), NPR = oproj_npr(D), NFP = NPM + NPR;
+  static constexpr int NPM = oproj_npm(D), NPR = oproj_npr(D), NFP = NPM + NPR;  // logical groups of the slot
+  static constexpr int NFPP = NPM + cdiv(NPR, 8);                                // its 1 KiB pieces
 };
 
 // b + residual + LayerNorm of the wave's 32 rows, in registers.  acc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   constexpr int RPG = cdiv(4, CTA);  // accumulator registers (k pairs) one GEMM2 fragment group covers
   constexpr int NPM = C::NPM, NFP = C::NFP;
   static_assert(CT == 0 || 4 % CT == 0, "relu placement assumes CT in {1, 2, 4}");
-  static_assert(!OP || (CPS == 2 && C::AHEAD == 2 && NFP + PD <= NFS + PD && NFP <= C::SLOT_G && NG > 0 && CT > 0),
+  static_assert(!OP || (CPS == 2 && C::AHEAD == 2 && NFP + PD <= NFS + PD && C::NFPP <= C::SLOT_G && CT > 0),
                 "the fused form: two-chunk slots, ring one slot ahead of the barrier");
   __shared__ __align__(16) float lds[C::LDS_FLOATS];
 
@@ -388,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
            : i < 4 * D ? bo[i - 3 * D] : i < 5 * D ? gam1[i - 4 * D] : bet1[i - 5 * D];
   {
     const float* src = slot_src(0) + lane * 4;  // (the out-projection slot has NFP fragment groups, the rest is padding)
-    for (int g = wave; g < (OP ? NFP : C::SLOT_G); g += NW) dma_piece(src + g * 256, ring_base + g * 1024);
+    for (int g = wave; g < (OP ? C::NFPP : C::SLOT_G); g += NW) dma_piece(src + g * 256, ring_base + g * 1024);
   }
   float4 rin[CTA][4], rinrem[NRA];  // fused form: the layer input rows (LN1's residual)
   load_rows(X, xv, xrem);
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
     const float* slot = ringl;
     if (!OP) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(slot + NFC * 256 + 4 * (2 * t + half));
+      for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(slot + (SGC - 1) * 256 + 4 * (2 * t + half));
     }
 #pragma unroll
     for (int k = 0; k < PD; ++k) f[k] = *reinterpret_cast<const float4*>(slot + k * 256 + lane * 4);
@@ -489,11 +516,11 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
           }
           if (j == 1) {  // request group K + PD (of the next slot, a chunk slot, once past the end)
             const int KP = K + PD;
-            if (KP < NFP) f[KP] = *reinterpret_cast<const float4*>(slot + KP * 256 + lane_i * 4);
-            else f[KP] = *reinterpret_cast<const float4*>(nslot + (KP - NFP) * 256 + lane_i * 4);
+            if (KP < NFP) f[KP] = *reinterpret_cast<const float4*>(slot + ring_frag_off(NPM, KP, lane_i));
+            else f[KP] = *reinterpret_cast<const float4*>(nslot + ring_frag_off(C::NMAIN, KP - NFP, lane_i));
             if (K == NFP - 1) {
 #pragma unroll
-              for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(nslot + NFC * 256 + 4 * (2 * t + half_i));
+              for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(nslot + (SGC - 1) * 256 + 4 * (2 * t + half_i));
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -579,14 +606,19 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
             const int KP = K + PD;
             const float* base = KP < NFS ? slot : nslot;
             const int kk = KP < NFS ? KP : KP - NFS;
-            f[KP] = *reinterpret_cast<const float4*>(base + ((kk / NFC) * SGC + kk % NFC) * 256 + lane_i * 4);
+            f[KP] = *reinterpret_cast<const float4*>(base + (kk / NFC) * SGC * 256 + ring_frag_off(C::NMAIN, kk % NFC, lane_i));
             if (k == NFC - 1) {  // bias fragments of the next chunk (of the next slot after the last chunk)
-              const float* bsrc = (c + 1 < CPS) ? slot + ((c + 1) * SGC + NFC) * 256 : nslot + NFC * 256;
+              const float* bsrc = (c + 1 < CPS) ? slot + ((c + 1) * SGC + SGC - 1) * 256 : nslot + (SGC - 1) * 256;
 #pragma unroll
               for (int t = 0; t < 4; ++t) hb[t] = *reinterpret_cast<const float4*>(bsrc + 4 * (2 * t + half_i));
             }
           }
-          if (j == 2 && K >= (CPS - 1) * NFC + NQ1 && K < (CPS - 1) * NFC + NQ1 + C::NPW) issue_piece();
+          {  // this wave's NPW pieces of slot it + AHEAD: one per group from the barrier on (a second one per group where
+             // the groups left in the slot are fewer than the pieces: d_model 64 at four waves)
+            constexpr int KB0 = (CPS - 1) * NFC + NQ1, W = NFC - NQ1;
+            if (j == 2 && K >= KB0 && K - KB0 < C::NPW) issue_piece();
+            if (j == 3 && K >= KB0 && K - KB0 + W < C::NPW) issue_piece();
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
         if (k == NQ1 - 1) {
@@ -656,12 +688,15 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
   }
 }
 
+#ifndef FFD_ROWS_EXTRA_D
 int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
 int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
 int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
 int g_ffn_rows_fuse = 1;  // out-projection + LN1 inside the kernel (ffd_tune "ffn_rows_fuse"; two-chunk slots only)
 
-bool ffn_rows_supported(int D, int F) { return D == 72 && F % 64 == 0 && F >= 64; }
+// d_model values with an instance (round 4: 48, 60 -- the reference's class default, score_models.py:31 -- and 64 beside
+// 72; the compacted remainder groups are what fits d_model 60's seven of them into the ring)
+bool ffn_rows_supported(int D, int F) { return (D == 72 || D == 64 || D == 60 || D == 48) && F % 64 == 0 && F >= 64; }
 // large M: where k_ffn_ln ran its 64-row persistent form
 bool ffn_rows_selected(int M, int D, int F) {
   return g_ffn_rows && ffn_rows_supported(D, F) && (g_ffn_rows == 2 || cdiv(M, 64) >= 512);
@@ -670,6 +705,8 @@ bool ffn_rows_selected(int M, int D, int F) {
 bool ffn_rows_fused_selected(int M, int D, int F) {
   return g_ffn_rows_fuse && g_ffn_rows_cps != 1 && ffn_rows_selected(M, D, F);
 }
+
+#endif
 
 // y = LayerNorm2(sum over slices of the partial rows, in slice order): one row per 32 lanes (18 of them hold a float4 at
 // d_model 72), 8 rows per workgroup.  HBM-bound: (nslice + 1) D 4 bytes per row.
@@ -706,6 +743,7 @@ __global__ __launch_bounds__(256) void k_rows_reduce_ln(const float* __restrict_
   }
 }
 
+#ifndef FFD_ROWS_EXTRA_D
 int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuristic, -1 off, 2 / 4 / 8 / 16 forced (ffd_tune "rows_slices")
 
 // Mid-size M: (waves per workgroup, slices) of the sliced form, or false where another form is expected to be faster.
@@ -719,7 +757,8 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
   for (int nw = 8; nw <= 12; nw += 4) {
     if (g_ffn_rows_nw && g_ffn_rows_nw != nw) continue;
     const int tiles = cdiv(M, 32 * nw);
-    const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots, p_us = nw == 12 ? 10.0 : 7.0;
+    // (measured at d_model 72; the matrix cycles of a slot go with d_model)
+    const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots * (D / 72.0), p_us = (nw == 12 ? 10.0 : 7.0) * (D / 72.0);
     const int smax = nslots < 16 ? nslots : 16;
     for (int sl = 2; sl <= smax; ++sl) {
       if (g_rows_slices > 0 && g_rows_slices != sl) continue;
@@ -739,7 +778,7 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
     if (ffn_rows_selected(M, D, F)) {
       alt = 1e30;
       for (int nw = 4; nw <= 12; nw += 4) {
-        const double loop = nw == 12 ? 392.0 : nw == 8 ? 271.0 : 146.0;
+        const double loop = (nw == 12 ? 392.0 : nw == 8 ? 271.0 : 146.0) * (D / 72.0);
         alt = fmin(alt, cdiv(cdiv(M, 32 * nw), num_cus()) * (loop + 10.0) + 15.0);
       }
     }
@@ -749,6 +788,8 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
   return true;
 }
 size_t rows_slice_floats(int M, int D, int nslice) { return (size_t)nslice * M * D; }
+
+#endif
 
 struct RowsArgs {
   const float *X, *Rin;  // fused: attention output + layer input; else the FFN input (Rin unused)
@@ -804,9 +845,8 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int nw_forced = 0) {
-  if (a.M <= 0) return hipSuccess;
-  if (!ffn_rows_supported(D, a.F) || a.w->ring == nullptr || (a.fused && a.w->ring_op == nullptr)) return hipErrorInvalidValue;
+template <int D>
+hipError_t launch_rows_d(const RowsArgs& a, hipStream_t s, int nw_forced) {
   // Waves per workgroup: a tile is 32 NW rows and every CU walks ceil(tiles / CUs) of them at NW / 4 waves per SIMD.
   // Pick the NW with the least estimated time = passes x waves per SIMD / measured main-loop efficiency
   // (tools/ffn_rows_sweep.py at the ECG B = 512 shape: 0.85 / 0.915 / 0.938 of the matrix pipe at 1 / 2 / 3 waves per
@@ -822,13 +862,38 @@ static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int n
     }
   }
   const int cps = g_ffn_rows_cps == 1 ? 1 : 2;  // 32-unit chunks per ring slot = per barrier (ffd_tune "ffn_rows_cps")
-  switch (nw * 10 + cps) {
-    case 41: return launch_rows_cfg<72, 4, 1, 4>(a, s);
-    case 42: return launch_rows_cfg<72, 4, 2, 3>(a, s);
-    case 81: return launch_rows_cfg<72, 8, 1, 4>(a, s);
-    case 82: return launch_rows_cfg<72, 8, 2, 3>(a, s);
-    case 121: return launch_rows_cfg<72, 12, 1, 4>(a, s);
-    default: return launch_rows_cfg<72, 12, 2, 3>(a, s);
+  if constexpr (D == 72) {  // (one-chunk slots: an experiment knob of the d_model 72 instances only)
+    if (cps == 1) {
+      switch (nw) {
+        case 4: return launch_rows_cfg<72, 4, 1, 4>(a, s);
+        case 8: return launch_rows_cfg<72, 8, 1, 4>(a, s);
+        default: return launch_rows_cfg<72, 12, 1, 4>(a, s);
+      }
+    }
+  }
+  switch (nw) {
+    case 4: return launch_rows_cfg<D, 4, 2, 3>(a, s);
+    case 8: return launch_rows_cfg<D, 8, 2, 3>(a, s);
+    default: return launch_rows_cfg<D, 12, 2, 3>(a, s);
+  }
+}
+
+#ifdef FFD_ROWS_EXTRA_D
+template hipError_t launch_rows_d<FFD_ROWS_EXTRA_D>(const RowsArgs&, hipStream_t, int);
+#else
+// (d_model 64 / 60 / 48: instantiated in ffd_ffn_rows_d64.hip / _d60 / _d48, which compile this file with FFD_ROWS_EXTRA_D set -- in parallel)
+extern template hipError_t launch_rows_d<64>(const RowsArgs&, hipStream_t, int);
+extern template hipError_t launch_rows_d<60>(const RowsArgs&, hipStream_t, int);
+extern template hipError_t launch_rows_d<48>(const RowsArgs&, hipStream_t, int);
+static hipError_t launch_rows_any(const RowsArgs& a, int D, hipStream_t s, int nw_forced = 0) {
+  if (a.M <= 0) return hipSuccess;
+  if (!ffn_rows_supported(D, a.F) || a.w->ring == nullptr || (a.fused && a.w->ring_op == nullptr)) return hipErrorInvalidValue;
+  switch (D) {
+    case 72: return launch_rows_d<72>(a, s, nw_forced);
+    case 64: return launch_rows_d<64>(a, s, nw_forced);
+    case 60: return launch_rows_d<60>(a, s, nw_forced);
+    case 48: return launch_rows_d<48>(a, s, nw_forced);
+    default: return hipErrorInvalidValue;
   }
 }
 
@@ -847,13 +912,20 @@ hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const Laye
 // The same for mid-size M as tiles x nslice units + the reduce / LN2 launch; P holds nslice x M x D floats.
 hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, const LayerWeights& w, float* P, float* Y,
                                         int M, int D, int F, int nw, int nslice, hipStream_t s) {
-  if (D != 72 || nslice < 2) return hipErrorInvalidValue;
+  if (!ffn_rows_supported(D, F) || nslice < 2) return hipErrorInvalidValue;
   RowsArgs a{attn, Rin, &w, P, M, F, true, nullptr};
   a.nslice = nslice;
   const hipError_t e = launch_rows_any(a, D, s, nw);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_rows_reduce_ln<72>, dim3(cdiv(M, 8)), dim3(256), 0, s, P, nslice, M, w.n2w, w.n2b, Y);
+  switch (D) {
+#define X(d) case d: hipLaunchKernelGGL(k_rows_reduce_ln<d>, dim3(cdiv(M, 8)), dim3(256), 0, s, P, nslice, M, w.n2w, w.n2b, Y); break;
+    X(72) X(64) X(60) X(48)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
+
+#endif
 
 }  // namespace ffd

@@ -7,6 +7,7 @@ Tolerances (fp32):
   score evaluation : <= 1e-5 x output max-norm
   trajectories     : <= 1e-5 x max-norm at up to 1000 steps with injected noise
 """
+import ctypes as C_
 import math
 import time
 
@@ -427,6 +428,45 @@ def test_model_full_batch_properties(ffd):
     t = torch.full((4,), 0.6, dtype=torch.float32)
     ref = O.score_forward(x[100:104], t, sd, c["NL"], c["H"])
     assert rel_err(out[100:104], ref) < TOL_SCORE
+
+
+@pytest.mark.parametrize("d,H", [(60, 12), (64, 8), (48, 12)])
+def test_rows_kernel_other_d_models_at_size(ffd, d, H):
+    """Round 4: k_ffn_rows (row-owning waves under the LDS weight ring, out-projection + LN1 inside) instantiated for
+    d_model 60 -- the reference's class default, score_models.py:31 -- 64 and 48.  At the ECG length and B = 512 (the
+    production selection there: large M): sample independence, a slice against the oracle, and the same bits for every
+    waves-per-workgroup choice, the sliced form to rounding, the F-split kernel it replaces (k_ffn_ln) to rounding."""
+    from fastfourierdiffusion_amd import _native as N
+
+    L, C, NL, B = 187, 1, 3, 512
+    c = dict(kind="transformer", d=d, H=H, NL=NL, L=L, C=C, sde="vp", sde_kwargs=cases.VP, fourier=True, wseed=700 + d)
+    m, _ = make_model(ffd, c)
+    sd = make_sd(c)
+    lib = N.lib()
+    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, 4400 + d)))
+    fl, by = C_.c_double(), C_.c_double()
+    name = lib.ffd_kernel_work(m._ctx().handle, N.K_FFN, B, 0, C_.byref(fl), C_.byref(by)).decode()
+    assert name.startswith("k_ffn_rows<oproj"), name  # the production selection at this size
+    out = m(batch_of(x.cuda(), 0.6))
+    assert torch.isfinite(out).all()
+    t = torch.full((3,), 0.6, dtype=torch.float32)
+    assert rel_err(out[200:203].cpu(), O.score_forward(x[200:203], t, sd, NL, H)) < TOL_SCORE
+    for b in (0, 511):
+        one = m(batch_of(x[b:b + 1].cuda(), 0.6)).cpu()  # (small-batch kernels: other summation order)
+        assert rel_err(out[b:b + 1].cpu(), one) < 2e-6, b
+    for nw in (4, 8, 12):
+        for fuse in (1, 0):
+            assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"ffn_rows_fuse", fuse) == 0
+            o2 = m(batch_of(x.cuda(), 0.6))
+            if fuse:
+                assert torch.equal(o2, out), (nw, fuse)
+            else:
+                assert rel_err(o2.cpu(), out.cpu()) < 2e-6, (nw, fuse)
+    assert lib.ffd_tune(b"reset", 0) == 0
+    assert lib.ffd_tune(b"rows_slices", 3) == 0 and lib.ffd_tune(b"ffn_rows_nw", 12) == 0
+    assert rel_err(m(batch_of(x[:100].contiguous().cuda(), 0.6)).cpu(), out[:100].cpu()) < 2e-6
+    assert lib.ffd_tune(b"reset", 0) == 0 and lib.ffd_tune(b"ffn_rows", 0) == 0
+    assert rel_err(m(batch_of(x.cuda(), 0.6)).cpu(), out.cpu()) < 2e-6
 
 
 def test_lstm_full_batch_properties(ffd):
