@@ -245,7 +245,7 @@ def cpu_baseline(sd, L, Cn, NL, H, kind):
         tv = ts[i].item()
         t = torch.full((B,), tv)
         if kind == "lstm":
-            score = O.lstm_score_forward(x, t, sdt, NL)
+            score = O.lstm_score_forward_stock(x, t, sdt, NL)
         else:
             score = O.score_forward_stock(x, t, sdt, NL, H)
         x = O.vp_step(x, score, torch.randn(B, L, Cn, generator=g), tv, G, dt)
@@ -253,7 +253,7 @@ def cpu_baseline(sd, L, Cn, NL, H, kind):
             t_acc += time.perf_counter() - t0
     s_per_step = t_acc / steps
     return {"value": B / (1000.0 * s_per_step), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch-CPU fp32{'' if kind == 'lstm' else ', stock nn.TransformerEncoder backbone = the fused path the reference runs'}), B={B}, {steps} of 1000 steps timed after {warm} warm-up, x(1000/{steps})",
+            "sample": f"oracle (torch-CPU fp32, stock {'nn.LSTM layers' if kind == 'lstm' else 'nn.TransformerEncoder backbone'} = the fused path the reference runs), B={B}, {steps} of 1000 steps timed after {warm} warm-up, x(1000/{steps})",
             "reference_speed_over_port": None if kind == "lstm" else _ref_over_port(),
             "reference_speed_source": "profiles/r04_reference_cpu_timing.json (unmodified reference vs this port, B=32 step, build container)",
             "ms_per_step": s_per_step * 1e3}

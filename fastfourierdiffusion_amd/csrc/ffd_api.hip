@@ -204,12 +204,12 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
-    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144, g_lstm_mfma_min_batch = 1 << 30,
-    g_lstm_mfma_s = 0, g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
+    g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144,
+    g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return FFD_ERR_INVALID;
+    if (value != 0 && value != 1 && value != 2 && value != 4) return FFD_ERR_INVALID;
     g_ffn_mb_override = value;
     return FFD_OK;
   }
@@ -278,12 +278,7 @@ int ffd_tune(const char* key, int value) {
     g_ffn_rem = value ? 1 : 0;
     return FFD_OK;
   }
-  if (!strcmp(key, "lstm_mfma_min_batch")) {  // batch from which the batch-tiled MFMA recurrence is used
-    if (value < 1) return FFD_ERR_INVALID;
-    g_lstm_mfma_min_batch = value;
-    return FFD_OK;
-  }
-  if (!strcmp(key, "lstm_wave")) {  // LSTM layers as a wavefront below the k_lstm_mfma crossover: 1 | 0 | 2 (every batch)
+  if (!strcmp(key, "lstm_wave")) {  // LSTM layers as a wavefront (1, default; 2 = the same) | 0: the per-layer kernels
     if (value < 0 || value > 2) return FFD_ERR_INVALID;
     g_lstm_wave = value;
     return FFD_OK;
@@ -310,11 +305,6 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "lstm_wave_spin_ms")) {  // time limit of one wait on a progress word
     if (value < 1 || value > 20000) return FFD_ERR_INVALID;
     g_lstm_wave_spin_ms = value;
-    return FFD_OK;
-  }
-  if (!strcmp(key, "lstm_mfma_s")) {  // 16-sample tiles per workgroup of that kernel (0 = by batch)
-    if (value < 0 || value > 2) return FFD_ERR_INVALID;
-    g_lstm_mfma_s = value;
     return FFD_OK;
   }
   if (!strcmp(key, "fuse_tail")) {  // unembed inside the SDE-step kernel of ffd_sample_batch
@@ -729,10 +719,6 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
     } else
     for (int i = 0; i < m.num_layers; ++i) {
       const LstmLayer& l = ctx->lstm[i];
-      if (lstm_mfma_selected(B, d)) {  // batch-tiled MFMA recurrence with the input gates fused
-        TIMED(FFD_K_LSTM_REC, launch_lstm_mfma(ctx->h0, l.wih, l.whh, l.bsum, B, L, d, s));
-        continue;
-      }
       if (int rc = ensure_qkv(ctx, (size_t)M * 4 * d)) return rc;  // gate pre-activations gx
       TIMED(FFD_K_LSTM_GATES, launch_linear(ctx->h0, l.wih_p, l.bsum, ctx->qkv, M, 4 * d, d, 4 * d, s));
       TIMED(FFD_K_LSTM_REC, launch_lstm_layer(ctx->h0, ctx->qkv, l.whh, B, L, d, s));
@@ -1424,13 +1410,11 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
         const double Ml = (double)(B < lstm_wave_max_batch(L, m.d_model) ? B : lstm_wave_max_batch(L, m.d_model)) * L;
         name = "k_lstm_wave", fl = m.num_layers * 2.0 * Ml * 8.0 * d * d, by = m.num_layers * 4.0 * (2.0 * Ml * d + 8.0 * d * d);
       }
-      else if (ls && lstm_mfma_selected(B, m.d_model))  // x W_ih^T + h W_hh^T for L cell steps; rows in, rows out
-        name = "k_lstm_mfma", fl = 2.0 * M * 8.0 * d * d, by = 4.0 * (2.0 * M * d + 8.0 * d * d);
       else if (ls)  // h W_hh^T for L cell steps; gate pre-activations + residual rows in, rows out
         name = "k_lstm_layer", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * 4.0 * d + 2.0 * M * d + 4.0 * d * d);
       break;
     case FFD_K_LSTM_GATES:
-      if (ls && !lstm_mfma_selected(B, m.d_model) && !lstm_wave_selected(B, m.d_model))
+      if (ls && !lstm_wave_selected(B, m.d_model))
         name = "k_linear_rm", fl = 2.0 * M * 4.0 * d * d, by = 4.0 * (M * d + M * 4.0 * d + 4.0 * d * d);
       break;
     case FFD_K_SDE:

@@ -431,7 +431,8 @@ int num_cus() {
   return n;
 }
 int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
-int g_ffn_mb_override = 0;  // 0 = heuristic; 1/2/4/8 forces the tile height (ffd_tune "ffn_mb")
+int g_ffn_mb_override = 0;  // 0 = heuristic; 1 / 2 / 4 forces the tile height (ffd_tune "ffn_mb"; the 128-row MB = 8 instances -- never
+                            // selected, 400-656 B of scratch at d_model >= 48 -- were retired in round 4)
 
 template <int D>
 static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, int M, int F, hipStream_t s,
@@ -439,7 +440,7 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
   // and is the default once the grid fills the chip; smaller tiles for small batches.
   int mb = g_ffn_mb_override;
-  if (mb != 1 && mb != 2 && mb != 4 && mb != 8) {
+  if (mb != 1 && mb != 2 && mb != 4) {
     const int target = 2 * 256;
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
   }
@@ -460,7 +461,6 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
                          w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp);                                      \
   } while (0)
   switch (mb) {
-    case 8: FFD_LAUNCH_FFN(8); break;
     case 4: FFD_LAUNCH_FFN(4); break;
     case 2: FFD_LAUNCH_FFN(2); break;
     default: FFD_LAUNCH_FFN(1); break;
@@ -471,7 +471,7 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
 
 int ffn_tile_rows(int M) {  // rows per workgroup launch_ffn_ln picks (one stamp pair per workgroup)
   int mb = g_ffn_mb_override;
-  if (mb != 1 && mb != 2 && mb != 4 && mb != 8) mb = cdiv(M, 64) >= 512 ? 4 : cdiv(M, 32) >= 512 ? 2 : 1;
+  if (mb != 1 && mb != 2 && mb != 4) mb = cdiv(M, 64) >= 512 ? 4 : cdiv(M, 32) >= 512 ? 2 : 1;
   return 16 * mb;
 }
 

@@ -204,11 +204,6 @@ hipError_t launch_kv_store(const float* k, const float* v, float* kt, float* vt,
 // crf[l][:] <- h[l][:] for sample 0 is a plain D2D copy (done with hipMemcpyAsync)
 
 hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B, int L, int D, hipStream_t s);
-// large batches: input gates + recurrence of one residual LSTM layer in one launch (no gx tensor); in place on x
-bool lstm_mfma_selected(int B, int D);
-extern int g_lstm_mfma_min_batch, g_lstm_mfma_s;
-hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
-                            hipStream_t s);
 // batches below that kernel's crossover: all layers as a wavefront of (16-sample tile, layer) workgroups, in place on x;
 // prog: >= 16 + 16 * ceil(B / 16) ints of device scratch (abort word + progress words, cleared by the launcher);
 // err: host-visible word that receives 1 + (unit index) when a wait on a progress word runs out of time

@@ -184,230 +184,32 @@ __global__ __launch_bounds__(((4 * D + 63) / 64) * 64, (4 * D > 256 ? 4 : 1)) vo
 }
 
 // ---------------------------------------------------------------------------
-// Large batches: batch-tiled recurrence on the exact-fp32 matrix core, input gates fused.
+// The cell step on the exact-fp32 matrix core (the building block of k_lstm_wave below; until round 4 also a kernel of
+// its own, k_lstm_mfma, one layer per launch -- retired once the wavefront was pinned by the 1000-step golden: it was the
+// slower or equal form at every batch size).
 //
-// A group of 4 waves (one per SIMD) owns 16 samples for the whole sequence; a workgroup holds GRP such groups.  Per
-// cell step the gate pre-activations of the 16-sample tile are
+// A 16-sample tile is advanced one cell step by
 //     G^T (4d x 16) = W_ih x_t^T + W_hh h_{t-1}^T + b          on v_mfma_f32_16x16x4_f32
-// with the WEIGHTS as the A operand: each wave keeps the W_hh fragments of its own 16-row tiles in VGPRs for all L
-// steps (5 x 18 registers at d = 72; biases too) and streams its W_ih fragments from a wave-private LDS image (one ds_read_b128
-// per 4 k-steps) -- neither matrix is re-read from memory, and the (B, L, 4d) gate tensor of the small-batch path
+// with the WEIGHTS as the A operand: a wave keeps the fragments of its own 16-row tiles in VGPRs for all the steps it
+// runs (5 x 18 registers at d = 72; biases too) -- neither matrix is re-read from memory, and a (B, L, 4d) gate tensor
 // (185 MB per 512 samples and layer) never exists.
 // Row order inside a 16-row tile is (unit, gate) = (i >> 2, i & 3): the accumulator D[i = 4 (l >> 4) + r][j = l & 15]
 // then leaves lane l with all FOUR gates (r = i, f, g, o) of unit 4 T + (l >> 4) for sample (l & 15) -- the cell update
-// is lane-local and c lives in a register.  Waves own disjoint unit tiles (18 tiles over 4 waves: 5 / 5 / 4 / 4; the
-// 4-tile waves run a phantom tile on zero weights, the step is paced by the 5-tile SIMDs anyway), so h is exchanged
-// through a double-buffered LDS image with one rendezvous per step.
-// x_t never travels as fragments: the group's 256 threads move the tile's 16 rows (16 x d floats) per step as whole
-// float4 -- HBM -> registers three steps ahead, registers -> a 3-slot ring of LDS row images two steps ahead, B fragments
-// from the image like h -- and write x_t + h_t back the same way one step later (x_t from its ring slot, h_t rows from
-// the h image).  Fragment-shaped global accesses (16 rows x 16 B per instruction, every wave re-reading the rows) cost
-// 27 % of the step.
-// GRP = 2: waves w and w + 4 own the SAME unit tiles for two different sample groups and share a SIMD and the W_ih /
-// bias image.  The groups are independent recurrences with their own per-step rendezvous (a monotonic LDS counter,
-// not s_barrier) and the second starts half a step late, so that one's cell update and waits sit under the other's
-// MFMAs instead of both wanting the matrix pipe, then the vector ALU, at the same moments.
+// is lane-local and c lives in a register.  Waves own disjoint unit tiles (18 tiles over 4 waves: 5 / 5 / 4 / 4), so h
+// is exchanged through a double-buffered LDS image with one rendezvous per step.
+// x_t never travels as fragments: 256 threads move the tile's 16 rows (16 x d floats) per step as whole float4 --
+// HBM -> registers three steps ahead, registers -> a 3-slot ring of LDS row images two steps ahead, B fragments from the
+// image like h -- and write x_t + h_t back the same way one step later (x_t from its ring slot, h_t rows from the h
+// image).  Fragment-shaped global accesses (16 rows x 16 B per instruction, every wave re-reading the rows) cost 27 %
+// of a step.
 // ---------------------------------------------------------------------------
-template <int D, int GRP>
-__global__ __launch_bounds__(256 * GRP, GRP) void k_lstm_mfma(float* __restrict__ x, const float* __restrict__ wih,
-                                                              const float* __restrict__ whh,
-                                                              const float* __restrict__ bsum, int B, int L) {
-  constexpr int NT = D / 4;          // unit tiles of 4 units x 4 gates == k-steps of 4
-  constexpr int NTW = (NT + 3) / 4;  // tiles per wave (upper bound)
-  constexpr int NG = (NT + 3) / 4;   // groups of 4 k-steps (one float4 of A fragments each)
-  constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
-  constexpr int NF4 = 16 * NT;       // float4 slots of a 16-row tile
-  constexpr int NSL = (NF4 + 255) / 256;  // slots per thread of a group
-  extern __shared__ __align__(16) float lds[];
-  float4* wlds = reinterpret_cast<float4*>(lds);  // [wave 4][g NG][tt NTW][lane 64]
-  float4* blds = wlds + 4 * NG * NTW * 64;        // end of the weight image
-  const int lane = threadIdx.x & 63;
-  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile ownership tests are s_cbranch
-  const int wave = wave8 & 3, grp = wave8 >> 2;
-  const int tg = threadIdx.x & 255;  // thread of the group
-  float* gbase = reinterpret_cast<float*>(blds) + grp * (5 * 16 * HS);
-  float* hbuf = gbase;                // [2][16][HS]  h_{t-1} / h_t
-  float* xbuf = gbase + 2 * 16 * HS;  // [3][16][HS]  x_t rows in slot t % 3
-  unsigned* gcnt = reinterpret_cast<unsigned*>(reinterpret_cast<float*>(blds) + GRP * (5 * 16 * HS)) + grp;
-  const int j = lane & 15, q = lane >> 4;
-  const int t0 = wave * (NT / 4) + min(wave, NT % 4);
-  const int ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
-
-  // weight fragments (A operand: lane holds W[row(T, i = lane & 15)][k = 4 s + q]) and biases (accumulator layout)
-  float wh[NTW][NT];
-  f32x4 bias[NTW];
-#pragma unroll
-  for (int tt = 0; tt < NTW; ++tt) {
-    const int T = min(t0 + tt, NT - 1);
-    const bool on = tt < ntw;
-    const size_t row = (size_t)((j & 3) * D + 4 * T + (j >> 2)) * D;
-#pragma unroll
-    for (int s = 0; s < NT; ++s) wh[tt][s] = on ? whh[row + 4 * s + q] : 0.f;
-    if (grp == 0) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        float4 v;
-        v.x = (on && 4 * g + 0 < NT) ? wih[row + 4 * (4 * g + 0) + q] : 0.f;
-        v.y = (on && 4 * g + 1 < NT) ? wih[row + 4 * (4 * g + 1) + q] : 0.f;
-        v.z = (on && 4 * g + 2 < NT) ? wih[row + 4 * (4 * g + 2) + q] : 0.f;
-        v.w = (on && 4 * g + 3 < NT) ? wih[row + 4 * (4 * g + 3) + q] : 0.f;
-        wlds[((wave * NG + g) * NTW + tt) * 64 + lane] = v;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * T + q] : 0.f;
-  }
-  for (int i = tg; i < 2 * 16 * HS; i += 256) hbuf[i] = 0.f;
-  if (tg == 0) *gcnt = 0u;
-  const float4* wl = wlds + (size_t)wave * NG * NTW * 64 + lane;
-
-  // this thread's float4 slots of the tile's rows: slot f -> row f / NT, columns 4 (f % NT) .. +3
-  const int b0 = (blockIdx.x * GRP + grp) * 16;
-  float* gp[NSL];   // global address of the slot at t = 0 (sample clamped; stores masked by `ok`)
-  int lo[NSL];      // LDS float offset of the slot inside a [16][HS] image
-  bool has[NSL], ok[NSL];
-#pragma unroll
-  for (int k = 0; k < NSL; ++k) {
-    const int f = tg + 256 * k;
-    has[k] = f < NF4;
-    const int r = min(f, NF4 - 1) / NT, c4 = min(f, NF4 - 1) - r * NT;
-    ok[k] = has[k] && b0 + r < B;
-    gp[k] = x + ((size_t)min(b0 + r, B - 1) * L) * D + 4 * c4;
-    lo[k] = r * HS + 4 * c4;
-  }
-  auto gload = [&](int t, float4 (&dst)[NSL]) {
-#pragma unroll
-    for (int k = 0; k < NSL; ++k)
-      if (has[k]) dst[k] = *reinterpret_cast<const float4*>(gp[k] + (size_t)t * D);
-  };
-  auto xput = [&](int par, const float4 (&src)[NSL]) {  // rows -> x ring slot `par` (8-byte aligned rows)
-#pragma unroll
-    for (int k = 0; k < NSL; ++k)
-      if (has[k]) {
-        float2* d2 = reinterpret_cast<float2*>(xbuf + par * 16 * HS + lo[k]);
-        d2[0] = float2{src[k].x, src[k].y};
-        d2[1] = float2{src[k].z, src[k].w};
-      }
-  };
-  // x_t + h_t -> global: x_t rows from ring slot `xs` (this thread's own float4s), h_t rows from h image `par`
-  auto out_store = [&](int t, int par, int xs) {
-#pragma unroll
-    for (int k = 0; k < NSL; ++k)
-      if (ok[k]) {
-        const float2* h2 = reinterpret_cast<const float2*>(hbuf + par * 16 * HS + lo[k]);
-        const float2* x2 = reinterpret_cast<const float2*>(xbuf + xs * 16 * HS + lo[k]);
-        const float2 a = h2[0], b = h2[1], u = x2[0], v = x2[1];
-        *reinterpret_cast<float4*>(gp[k] + (size_t)t * D) = float4{u.x + a.x, u.y + a.y, v.x + b.x, v.y + b.y};
-      }
-  };
-  // rendezvous of the group's four waves number `n` (1-based): every wave's LDS stores issued before its arrival
-  // are visible after it (LDS executes a wave's operations in order; fences keep hipcc from moving accesses across)
-  auto rendezvous = [&](unsigned n) {
-    if (GRP == 1) {
-      __syncthreads();
-    } else {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_fetch_add(gcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      while (__hip_atomic_load(gcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * n) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-  };
-  // acc = b + W_ih x_t for this wave's tiles, x_t fragments from x image `par`
-  auto input_part = [&](int par, f32x4 (&acc)[NTW]) {
-    float xf[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) xf[s] = xbuf[(par * 16 + j) * HS + 4 * s + q];
-#pragma unroll
-    for (int tt = 0; tt < NTW; ++tt) acc[tt] = bias[tt];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      float4 wv[NTW];
-#pragma unroll
-      for (int tt = 0; tt < NTW; ++tt) wv[tt] = wl[(g * NTW + tt) * 64];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = 4 * g + i;
-        if (s < NT) {
-#pragma unroll
-          for (int tt = 0; tt < NTW; ++tt) {
-            const float a = i == 0 ? wv[tt].x : i == 1 ? wv[tt].y : i == 2 ? wv[tt].z : wv[tt].w;
-            acc[tt] = mfma16(a, xf[s], acc[tt]);
-          }
-        }
-      }
-    }
-  };
-
-  float c[NTW];
-#pragma unroll
-  for (int tt = 0; tt < NTW; ++tt) c[tt] = 0.f;
-  // this thread's row slots in flight: xn = x_{t+2} (loaded a step ago, put into the ring this step)
-  float4 xn[NSL];
-  gload(0, xn);
-  xput(0, xn);
-  if (L > 1) {
-    gload(1, xn);
-    xput(1, xn);
-  }
-  if (L > 2) gload(2, xn);
-  __syncthreads();  // weight / bias / h / x images written (all groups)
-  if (GRP == 2 && grp == 1) __builtin_amdgcn_s_sleep(80);  // ~5k cycles: half a cell step out of phase with group 0
-  f32x4 acc[NTW];
-  input_part(0, acc);
-  int s0 = 0, s1 = 1, s2 = 2;  // ring slots of x_t, x_{t+1}, x_{t+2} (= the slot x_{t-1} occupied)
-  for (int t = 0; t < L; ++t) {
-    const int cur = t & 1;
-    rendezvous((unsigned)t + 1);  // h_{t-1} (h image cur) and x_{t+1} (ring slot s1) are complete
-    if (t > 0) out_store(t - 1, cur, s2);  // x_{t-1} + h_{t-1}
-    float hb[NT];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) hb[s] = hbuf[(cur * 16 + j) * HS + 4 * s + q];
-#pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-      for (int tt = 0; tt < NTW; ++tt) acc[tt] = mfma16(wh[tt][s], hb[s], acc[tt]);
-    // cell update, lane-local: (i, f, g, o) = acc[0..3] of unit 4 T + q, sample j
-#pragma unroll
-    for (int tt = 0; tt < NTW; ++tt)
-      if (tt < ntw) {
-        const f32x4 a = acc[tt];
-        const float gi = sigmoid_fast(a[0]), gf = sigmoid_fast(a[1]), gg = tanh_fast(a[2]), go = sigmoid_fast(a[3]);
-        c[tt] = gf * c[tt] + gi * gg;
-        hbuf[((cur ^ 1) * 16 + j) * HS + 4 * (t0 + tt) + q] = go * tanh_fast(c[tt]);
-      }
-    if (t + 1 < L) input_part(s1, acc);  // next step's input part: x_{t+1} fragments
-    // slot s2 held x_{t-1}: every wave read its fragments two steps ago and this thread just wrote its rows back
-    if (t + 2 < L) xput(s2, xn);
-    if (t + 3 < L) gload(t + 3, xn);
-    const int r = s0;
-    s0 = s1, s1 = s2, s2 = r;
-  }
-  rendezvous((unsigned)L + 1);
-  out_store(L - 1, L & 1, s2);  // after the last rotation s2 is the slot of x_{L-1}; h_{L-1} sits in h image L & 1
-}
-
-constexpr size_t lstm_mfma_lds(int D, int GRP) {
-  const int NT = D / 4, NTW = (NT + 3) / 4, NG = (NT + 3) / 4;
-  return (size_t)(4 * NG * NTW * 64) * 16 + (size_t)GRP * 5 * 16 * (D + 2) * 4 + 16;
-}
-
-// Batch from which the batch-tiled kernel runs: never by default since round 3.  The layer wavefront (k_lstm_wave, a
-// 16-sample tile per CU, larger batches in sub-batches of 4096) is the faster or equal form at every batch (samples/s at
-// 1000 steps, wave | mfma: B = 1536 480 | 180, 2048 514 | 238, 4096 520 | 470, 8192 518 | 516, 10000 513 | 310,
-// 12288 518 | 387, 16384 517 | 518): the two tie where the batch fills the batch-tiled kernel's
-// rounds exactly, and in between it runs a whole extra round.  ffd_tune "lstm_mfma_min_batch" selects it (the test
-// suite runs every LSTM golden through it as the cross-check of the wavefront).
-int g_lstm_mfma_min_batch = 1 << 30;
-int g_lstm_mfma_s = 0;  // 16-sample groups per workgroup: 0 = by batch, 1, 2
-
-bool lstm_mfma_selected(int B, int D) { return B >= g_lstm_mfma_min_batch && D % 4 == 0 && D >= 16; }
 
 // ---------------------------------------------------------------------------
 // Mid-size batches (16-sample tiles fit the chip once per layer group): the layers as a WAVEFRONT in one launch.
 //
 // Layer l at cell step t needs layer l-1 at step t and its own step t-1: the critical path of NL layers is
-// L + (NL - 1) * lag cell steps, not NL * L.  One workgroup per (16-sample tile, layer) runs k_lstm_mfma's cell step
-// (GRP = 1) over the whole sequence, in place on the same (B, L, d) buffer: a row passes through the layers in
+// L + (NL - 1) * lag cell steps, not NL * L.  One workgroup per (16-sample tile, layer) runs the cell step above
+// over the whole sequence, in place on the same (B, L, d) buffer: a row passes through the layers in
 // order, each adding its h_t.  Layer l's workgroup publishes its progress every CHP steps -- rows leave as
 // write-through (sc1) stores, every wave waits for its own stores, the step's workgroup barrier, then ONE lane stores
 // the step count (sc1) -- and layer l+1's workgroup of the same tile polls that word from one wave, joins its own
@@ -741,7 +543,7 @@ int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
 int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
 int g_lstm_wave_fault = 0;    // tests: unit fault - 1 never publishes its progress (the waits on it must time out as an ERROR)
 int g_lstm_wave_spin_ms = 2000;  // time limit of one wait on a progress word (ffd_tune "lstm_wave_spin_ms")
-int g_lstm_wave = 1;  // 1: layer-wavefront kernel for batches below the k_lstm_mfma crossover; 0: never; 2: at every batch (tests)
+int g_lstm_wave = 1;  // 1 (or 2): the layer-wavefront kernel, the LSTM path at every batch; 0: the per-layer kernels k_linear_rm + k_lstm_layer (tests' cross-check)
 
 // (batches past a 16-sample tile per CU go through the launcher in sub-batches of 16 CUs samples)
 // ... and so that a sub-batch's rows stay inside one raw-buffer resource (< 2^31 bytes; long sequences)
@@ -750,10 +552,7 @@ int lstm_wave_max_batch(int L, int D) {
   const long long by_cus = 16ll * num_cus();
   return (int)(by_bytes < by_cus ? by_bytes : by_cus);
 }
-bool lstm_wave_selected(int B, int D) {
-  if (g_lstm_wave == 0 || D % 4 != 0 || D < 16) return false;
-  return g_lstm_wave == 2 || !lstm_mfma_selected(B, D);
-}
+bool lstm_wave_selected(int B, int D) { return g_lstm_wave != 0 && D % 4 == 0 && D >= 16; }
 
 // floats of the state blocks (h rows + cell values per recurrent lane) of the time-chunked form, <= 16 layers per launch
 size_t lstm_wave_state_floats(int B, int D, int NL) {
@@ -836,35 +635,6 @@ hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* cons
   switch (D) {
 #define X(d) \
   case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, err, s);
-    X(16) X(24) X(32) X(48) X(60) X(64) X(72)
-#undef X
-    default: return hipErrorInvalidValue;
-  }
-}
-
-template <int D, int GRP>
-static hipError_t launch_lstm_mfma_t(float* x, const float* wih, const float* whh, const float* bsum, int B, int L,
-                                     hipStream_t s) {
-  constexpr size_t lds = lstm_mfma_lds(D, GRP);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_mfma<D, GRP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((k_lstm_mfma<D, GRP>), dim3(cdiv(B, 16 * GRP)), dim3(256 * GRP), lds, s, x, wih, whh, bsum, B, L);
-  return hipGetLastError();
-}
-
-hipError_t launch_lstm_mfma(float* x, const float* wih, const float* whh, const float* bsum, int B, int L, int D,
-                            hipStream_t s) {
-  if (B <= 0) return hipSuccess;
-  if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return hipErrorInvalidValue;
-  // 16 samples per workgroup (4 waves) while the 16-sample tiles do not exceed the CU count; beyond that two
-  // independent 4-wave groups per workgroup (ffd_tune "lstm_mfma_s": 1 / 2 forces either)
-  const bool two = g_lstm_mfma_s ? g_lstm_mfma_s == 2 : B > 16 * 256;
-  switch (D) {
-#define X(d) \
-  case d: return two ? launch_lstm_mfma_t<d, 2>(x, wih, whh, bsum, B, L, s) : launch_lstm_mfma_t<d, 1>(x, wih, whh, bsum, B, L, s);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;

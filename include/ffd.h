@@ -287,7 +287,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
 
 /* Process-wide tuning knobs for experiments and for the test suite's kernel variants (results stay within the
  * parity tolerance, only the kernel choice / tiling changes):
- *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4 | 8   rows/16 per workgroup of the fused FFN;
+ *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4       rows/16 per workgroup of k_ffn_ln;
  *   "reset" (value ignored)                    every knob below back to its default;
  *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
@@ -313,12 +313,12 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "attn_small" = 1 | 0 | 2 | 4               small batches: several workgroups per (sample, head), the key range of a
  *                                              q-tile cut into 2 / 4 pieces over the waves (1 = by batch size, 0 = never);
  *   "ffn_rem" = 1 | 0                          d%16 remainder rows of GEMM2 on the 4x4x1 MFMA;
- *   "lstm_mfma_min_batch" = n                  batch from which the LSTM recurrence runs on the batch-tiled k_lstm_mfma
- *                                              (default 2^30: never; the layer wavefront is faster or equal everywhere);
- *   "lstm_mfma_s" = 0 (by batch) | 1 | 2       16-sample tiles per workgroup of that kernel;
- *   "lstm_wave" = 1 | 0 | 2                    LSTM below that batch: all layers as a wavefront of (16-sample tile, layer)
- *                                              workgroups (k_lstm_wave), or the per-layer kernels (0); 2 = at every
- *                                              batch (test suite);
+ *   "lstm_wave" = 1 | 0                        LSTM: all layers as a wavefront of (16-sample tile, layer) workgroups
+ *                                              (k_lstm_wave, every batch), or the per-layer kernels (0: the test
+ *                                              suite's cross-check; 2 is accepted and means 1);
+ *   "lstm_wave_fault" = n, "lstm_wave_spin_ms" = ms   tests: unit n - 1 of k_lstm_wave withholds its progress word / the
+ *                                              time limit of one wait on such a word (see ffd_async_status);
+ *   "fail_alloc_after" = n                     tests: the n-th device allocation from now fails with FFD_ERR_NOMEM;
  *   "lstm_wave_persist" = 1 | 0                one launch whose resident workgroups run (chunk, layer, tile) units in
  *                                              index order, or one launch per group of `per` layers;
  *                                              "lstm_wave_per" = n: at most n layers in flight (0 = as many as the CUs

@@ -489,8 +489,8 @@ def test_lstm_full_batch_properties(ffd):
 
 def test_lstm_production_batch_selection(ffd):
     """BASELINE configs[3] shape at the batches the production selection (no ffd_tune here) hands to its two large-batch
-    form, the layer wavefront (k_lstm_wave: a 16-sample tile per CU, larger batches in sub-batches of 4096; the
-    batch-tiled k_lstm_mfma is the cross-check kernel of the test suite since round 3): B = 2048 and B = 4352.  Sample independence against small-batch evaluations for three picks, a
+    form, the layer wavefront (k_lstm_wave: a 16-sample tile per CU, larger batches in sub-batches of 4096): B = 2048 and
+    B = 4352.  Sample independence against small-batch evaluations for three picks, a
     two-sample slice against the oracle, and the kernel class bench.py would report."""
     import ctypes as C
 
@@ -1181,7 +1181,7 @@ def test_fused_unembed_sde_tail_equals_two_kernels(ffd, name):
 @pytest.mark.parametrize("name", ["nasa_lstm", "small_lstm", "refunit_lstm"])
 def test_lstm_wavefront_golden(ffd, golden, name):
     """The LSTM layers as a wavefront of (16-sample tile, layer) workgroups in one launch (k_lstm_wave: the production
-    selection below the k_lstm_mfma crossover, here pinned on with ffd_tune "lstm_wave" = 2) against the reference's
+    selection at every batch) against the reference's
     scores (g5), and against the per-layer kernels (ffd_tune "lstm_wave" = 0)."""
     from fastfourierdiffusion_amd import _native as N
 
@@ -1191,7 +1191,7 @@ def test_lstm_wavefront_golden(ffd, golden, name):
     lib = N.lib()
     x = torch.from_numpy(next(synthetic.noise_stream((c["B"], c["L"], c["C"]), 1, c["xseed"]))).cuda()
     for tv in c["t_values"]:
-        assert lib.ffd_tune(b"lstm_wave", 2) == 0
+        assert lib.ffd_tune(b"lstm_wave", 1) == 0
         w = m(batch_of(x, tv)).cpu()
         assert lib.ffd_tune(b"lstm_wave", 0) == 0
         per_layer = m(batch_of(x, tv)).cpu()
@@ -1258,65 +1258,6 @@ def test_lstm_wavefront_more_layers_than_a_launch_holds(ffd):
         n = min(2, B)
         ref = O.lstm_score_forward(x[:n], torch.full((n,), 0.6, dtype=torch.float32), sd, c["NL"])
         assert rel_err(outs[0][:n], ref) < TOL_SCORE, B
-
-
-@pytest.fixture
-def lstm_mfma(ffd):
-    """Force the batch-tiled MFMA recurrence (k_lstm_mfma: not selected in production since round 3, kept as the cross-check of the wavefront) on small batches."""
-    from fastfourierdiffusion_amd import _native as N
-
-    lib = N.lib()
-
-    def force(s):
-        assert lib.ffd_tune(b"lstm_mfma_min_batch", 1) == 0 and lib.ffd_tune(b"lstm_mfma_s", s) == 0
-
-    yield force
-    assert lib.ffd_tune(b"lstm_mfma_min_batch", 1 << 30) == 0 and lib.ffd_tune(b"lstm_mfma_s", 0) == 0
-
-
-@pytest.mark.parametrize("s_tiles", [1, 2])
-@pytest.mark.parametrize("name", ["nasa_lstm", "small_lstm"])
-def test_lstm_mfma_recurrence_golden(ffd, golden, lstm_mfma, name, s_tiles):
-    """The large-batch LSTM path (input gates + recurrence on v_mfma_f32_16x16x4_f32, weights resident in VGPRs,
-    16 or 32 samples per workgroup) against the reference goldens of LSTMScoreModule.forward (score_models.py:486-511),
-    at unchanged tolerances; d = 72 (18 unit tiles over 4 waves: 5/5/4/4) and d = 24 (6 tiles: 2/2/1/1)."""
-    lstm_mfma(s_tiles)
-    g = golden["g5_models"]
-    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
-    m, _ = make_model(ffd, c)
-    B, L, C = c["B"], c["L"], c["C"]
-    x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"]))).cuda()
-    for tv in c["t_values"]:
-        assert rel_err(m(batch_of(x, tv)).cpu(), g[f"{name}_score_t{tv}"]) < TOL_SCORE
-
-
-@pytest.mark.parametrize("s_tiles", [1, 2])
-def test_lstm_mfma_ragged_batch_and_independence(ffd, lstm_mfma, s_tiles):
-    """B = 37 (a partial last tile in both tilings): every sample equals its own evaluation on the one-sample-per-
-    workgroup kernel (other summation order: VALU quad split vs k-ordered MFMA chain), a slice equals the oracle, and
-    a 6-step trajectory (k_lstm_mfma + fused unembed / SDE tail) matches the small-batch kernels."""
-    from fastfourierdiffusion_amd import _native as N
-    from fastfourierdiffusion_amd.sampling.sampler import DiffusionSampler
-
-    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
-    m, _ = make_model(ffd, c)
-    sd = make_sd(c)
-    B = 37
-    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 4444)))
-    base = m(batch_of(x.cuda(), 0.45)).cpu()  # the small-batch form
-    noise = list(synthetic.noise_stream((B, c["L"], c["C"]), 7, 4445))
-    s0 = DiffusionSampler(m, B)
-    s0.inject_noise(iter(noise))
-    traj0 = s0.sample(B, 6)
-    lstm_mfma(s_tiles)
-    out = m(batch_of(x.cuda(), 0.45)).cpu()
-    assert torch.isfinite(out).all()
-    assert rel_err(out, base) < 5e-6
-    t = torch.full((3,), 0.45, dtype=torch.float32)
-    assert rel_err(out[34:37], O.lstm_score_forward(x[34:37], t, sd, c["NL"])) < TOL_SCORE
-    s1 = DiffusionSampler(m, B)
-    s1.inject_noise(iter(noise))
-    assert rel_err(s1.sample(B, 6), traj0) < TOL_TRAJ
 
 
 @pytest.mark.parametrize("B", [2048, 8192])

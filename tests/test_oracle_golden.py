@@ -313,10 +313,26 @@ def test_round4_traj_golden(golden, c):
     ck = c.get("cache_kwargs", {})
     out = O.sample(sd, kind=c["kind"], n_channels=C, max_len=L, num_layers=c["NL"], n_head=c["H"], sde=c["sde"],
                    sde_kwargs=c["sde_kwargs"], fourier_noise_scaling=c["fourier"], num_samples=c["num_samples"],
-                   batch_size=B, num_steps=N, noise=noise, use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10))
+                   batch_size=B, num_steps=N, noise=noise, use_cache=c["use_cache"], K=ck.get("K", 5), R=ck.get("R", 10),
+                   stock_modules=c["kind"] == "lstm" and N >= 1000)  # (2.5 M explicit cell steps would take minutes)
     ref = golden["g13_round4"][c["name"]]
     assert out.shape == ref.shape
     assert rel_err(out, ref) < TOL_TRAJ, rel_err(out, ref)
+
+
+def test_stock_lstm_form_equals_the_explicit_restatement(golden):
+    """The 1000-step LSTM trajectory check runs the oracle on stock nn.LSTM layers (torch's fused CPU LSTM): the same
+    function as the explicit cell loop, and it meets the same goldens."""
+    for name in ("nasa_lstm", "small_lstm"):
+        c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+        sd = make_sd(c)
+        B, L, C = c["B"], c["L"], c["C"]
+        x = torch.from_numpy(next(synthetic.noise_stream((B, L, C), 1, c["xseed"])))
+        for tv in c["t_values"]:
+            t = torch.full((B,), tv, dtype=torch.float32)
+            a = O.lstm_score_forward_stock(x, t, sd, c["NL"])
+            assert rel_err(a, O.lstm_score_forward(x, t, sd, c["NL"])) < TOL_KERNEL
+            assert rel_err(a, golden["g5_models"][f"{name}_score_t{tv}"]) < TOL_KERNEL * 5
 
 
 def test_stock_module_form_equals_the_explicit_restatement(golden):

@@ -10,7 +10,7 @@ wl = sys.argv[2] if len(sys.argv) > 2 else "ecg"
 model, sch, sd = bench.build_model(dev, wl)
 ctx = model._ctx(); lib = ctx.lib
 fl = lib.ffd_ffn_flops_per_launch(ctx.handle, B)
-res = {(mb, rem): [] for mb in (8, 4, 2, 1) for rem in (0, 1)}
+res = {(mb, rem): [] for mb in (4, 2, 1) for rem in (0, 1)}
 for rnd in range(5):
     for (mb, rem) in res:
         lib.ffd_tune(b"ffn_mb", mb)
