@@ -192,20 +192,42 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   // ------------------------------------------------------------------ phase 1: projection
   {
     const int n = lane & 15, qq = lane >> 4;
-    float4 wf[NCT][S4];
+    // One head of head_dim 6 is 18 features = one 16-wide tile + 2 (v[4], v[5]).  A second tile for those two would be
+    // seven eighths padding (576 matrix cycles per 16 tokens); instead every lane, which holds 18 of its token's 72 x
+    // values as A operand anyway, forms their partial dot products with the vector ALU (36 FMAs) and the four lanes of
+    // a token add theirs up (two xor-shuffles): ~180 cycles.  k order differs from the MFMA chain: rounding-level, in
+    // these two features only.
+    // (instances with >= 3 q-tiles per wave only: the others are built for 4 waves per SIMD = 128 registers, where the
+    //  36 weight registers of the two columns would spill)
+    constexpr bool VREM = HD == 6 && NCT == 2 && QG >= 3;
+    constexpr int NCTM = VREM ? 1 : NCT;  // feature tiles on the matrix core
+    float4 wf[NCTM][S4];
     const float4* Wq = reinterpret_cast<const float4*>(awp) + (size_t)h * NCT * S4 * 64;
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
+    for (int ct = 0; ct < NCTM; ++ct)
 #pragma unroll
       for (int j = 0; j < S4; ++j) wf[ct][j] = Wq[((size_t)ct * S4 + j) * 64 + lane];
+    float4 w16[VREM ? C16 : 1], w17[VREM ? C16 : 1];  // the second tile's columns n = 0, 1 for this lane's k subset (qq)
+    float2 w16r = {0.f, 0.f}, w17r = {0.f, 0.f};      // ... and its <= 2 remainder k-steps
     const float* abp = awp + (size_t)H * NCT * S4 * 256 + (size_t)h * NCT * 16;
-    float bias[NCT];
+    float b16 = 0.f, b17 = 0.f;
+    if constexpr (VREM) {
+#pragma unroll
+      for (int j = 0; j < C16; ++j) w16[j] = Wq[((size_t)S4 + j) * 64 + 16 * qq], w17[j] = Wq[((size_t)S4 + j) * 64 + 16 * qq + 1];
+      static_assert(!VREM || REM <= 2, "remainder k-steps of the two vector-ALU columns");
+      if constexpr (REM > 0) {
+        w16r = *reinterpret_cast<const float2*>(&Wq[((size_t)S4 + S4 - 1) * 64 + 16 * qq]);
+        w17r = *reinterpret_cast<const float2*>(&Wq[((size_t)S4 + S4 - 1) * 64 + 16 * qq + 1]);
+      }
+      b16 = abp[16], b17 = abp[17];
+    }
+    float bias[NCTM];
     // where this lane's feature (16 ct + n) goes, worked out once: float index of token 0 in the LDS images -- Q^T / K^T
     // rows take a lane's four tokens as one float4, V rows ([token][8]) as four scalars 8 floats apart; -1 = no feature
-    int sbase[NCT];
-    bool sv[NCT];
+    int sbase[NCTM];
+    bool sv[NCTM];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
+    for (int ct = 0; ct < NCTM; ++ct) {
       bias[ct] = abp[ct * 16 + n];
       const int fi = 16 * ct + n;
       const int reg = fi / HD, e = fi - reg * HD;
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int i = 0; i < REM; ++i) xr[i] = xp[16 * C16 + 4 * i + qq];
     };
     // x tiles are requested PFX tiles ahead: one tile's MFMAs take ~0.5 us, a global load 1-2 us
-    constexpr int PFX = 4;
+    constexpr int PFX = VREM ? 3 : 4;  // (three with the two vector-ALU columns' weights in registers: no scratch)
     float4 xa[PFX][C16 > 0 ? C16 : 1];
     float xr[PFX][REM > 0 ? REM : 1];
 #pragma unroll
@@ -242,13 +264,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       const int u = it % PFX;
       const int tt = wave + it * nwaves;
       if (tt >= TT) break;
-      f32x4 acc[NCT];
+      f32x4 acc[NCTM];
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int ct = 0; ct < NCTM; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < C16; ++j) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
+        for (int ct = 0; ct < NCTM; ++ct) {
           acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
           acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
           acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
@@ -258,17 +280,36 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll
       for (int i = 0; i < REM; ++i) {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
+        for (int ct = 0; ct < NCTM; ++ct) {
           const float4 w4 = wf[ct][S4 - 1];
           const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
           acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
         }
       }
+      float p16 = 0.f, p17 = 0.f;
+      if constexpr (VREM) {  // features 16, 17 of token n over this lane's k subset
+#pragma unroll
+        for (int j = 0; j < C16; ++j) {
+          p16 = fmaf(xa[u][j].x, w16[j].x, p16), p17 = fmaf(xa[u][j].x, w17[j].x, p17);
+          p16 = fmaf(xa[u][j].y, w16[j].y, p16), p17 = fmaf(xa[u][j].y, w17[j].y, p17);
+          p16 = fmaf(xa[u][j].z, w16[j].z, p16), p17 = fmaf(xa[u][j].z, w17[j].z, p17);
+          p16 = fmaf(xa[u][j].w, w16[j].w, p16), p17 = fmaf(xa[u][j].w, w17[j].w, p17);
+        }
+#pragma unroll
+        for (int i = 0; i < REM; ++i) {
+          p16 = fmaf(xr[u][i], i == 0 ? w16r.x : w16r.y, p16), p17 = fmaf(xr[u][i], i == 0 ? w17r.x : w17r.y, p17);
+        }
+      }
       if (it + PFX < MAXT) load_x(min(tt + PFX * nwaves, TT - 1), xa[u], xr[u]);  // refill this slot (clamped, unconditional)
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (VREM) {  // the token's four lanes (k subsets qq = 0 .. 3, 16 lanes apart) add up; qq = 0 stores v[4], v[5]
+        p16 += __shfl_xor(p16, 16), p17 += __shfl_xor(p17, 16);
+        p16 += __shfl_xor(p16, 32), p17 += __shfl_xor(p17, 32);
+        if (qq == 0) *reinterpret_cast<float2*>(vs + (size_t)(16 * tt + n) * 8 + 4) = float2{p16 + b16, p17 + b17};
+      }
       const int t0 = 16 * tt + 4 * qq;  // D: lane holds tokens t0 .. t0+3 of feature 16 ct + n
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
+      for (int ct = 0; ct < NCTM; ++ct) {
         const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
                                 acc[ct][3] + bias[ct]};
         if (sbase[ct] >= 0) {
