@@ -258,7 +258,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   constexpr int HS = D + 2;          // LDS row stride: HS / 2 odd -> the 16 rows x 2 k of a 32-lane half hit 32 banks
   constexpr int NF4 = 16 * NT;       // float4 slots of a 16-row tile
   constexpr int NSL = (NF4 + 255) / 256;  // slots per thread (of the 256 input-role threads)
-  constexpr int CHP = 2;             // cell steps between two publications of a layer's progress
+#ifndef FFD_LSTM_CHP
+#define FFD_LSTM_CHP 2
+#endif
+  constexpr int CHP = FFD_LSTM_CHP;  // cell steps between two publications of a layer's progress
   constexpr int SST = 16 * D + 4 * NTW * 64;  // floats of a (tile, layer) state block: h rows, then c per recurrent lane
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   extern __shared__ __align__(16) float lds[];

@@ -108,8 +108,22 @@ hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, i
   return hipGetLastError();
 }
 
+// max over the wave of a non-negative value: four DPP steps inside each row of 16 lanes, two xor-shuffles across the rows
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+#define FFD_DPP_MAX(ctrl) \
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, true)))
+  FFD_DPP_MAX(0xB1);   // quad_perm [1, 0, 3, 2]
+  FFD_DPP_MAX(0x4E);   // quad_perm [2, 3, 0, 1]
+  FFD_DPP_MAX(0x141);  // row_half_mirror
+  FFD_DPP_MAX(0x140);  // row_mirror
+#undef FFD_DPP_MAX
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+
 // Largest squared norm of the head's (scaled) q rows and of its k rows: nrm[0] keys, nrm[1] queries (as the bit patterns
-// of non-negative floats, which order like unsigned integers: one LDS atomic max per lane, no cross-lane reduction).
+// of non-negative floats, which order like unsigned integers: reduced inside the wave, then ONE LDS atomic max per wave
+// and value -- an atomic per lane serialises on the one address: 24 k cycles of the L = 512 kernel's 140 k when tried).
 // |q . k| <= |q| |k| bounds every score of the head; while that bound is within the threshold T the online softmax
 // needs no running maximum (its reference stays 0) and the key-tile loop skips the max reduction, the cross-half
 // exchange and the refresh test.  The caller zeroes nrm[0..1] before the barrier that precedes this call.
@@ -125,8 +139,11 @@ __device__ __forceinline__ void head_norms(const float* kts, const float* qts, u
     }
     km = fmaxf(km, k2), qm = fmaxf(qm, q2);
   }
-  atomicMax(nrm, __float_as_uint(km));
-  atomicMax(nrm + 1, __float_as_uint(qm));
+  km = wave_max_nonneg(km), qm = wave_max_nonneg(qm);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(nrm, __float_as_uint(km));
+    atomicMax(nrm + 1, __float_as_uint(qm));
+  }
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------
@@ -174,9 +191,10 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   }
   const int KT = (L + 31) >> 5;
   const int Lp = KT * 32;
-  // row stride of the LDS images: a compile-time 512 in the four-q-tiles-per-wave instance (launched for KT = 16 only), so
+  // row stride of the LDS images: a compile-time 516 in the four-q-tiles-per-wave instance (launched for KT = 16 only), so
   // that its LDS addresses are per-lane bases + immediate offsets; the run-time Lp elsewhere
-  const int LS = (QG == 4 && !SPLIT) ? 512 : Lp;
+  // (+ 4: a stride that is a multiple of 64 floats puts the 16 feature rows a projection tile stores into the same banks)
+  const int LS = (QG == 4 && !SPLIT) ? 516 : Lp + 4;
   float* vs = lds;                               // V   [Lp][8]
   float* kts = vs + (size_t)LS * 8;              // K^T [2*KST][LS]
   float* qts = kts + (size_t)2 * KST * LS;       // Q^T [2*KST][LS]   (already scaled by log2(e)/sqrt(hd))
@@ -631,11 +649,13 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   constexpr int S4 = (D + 15) / 16;
   constexpr int NW = 2 * HPW;           // waves per workgroup
   constexpr int MAXT = 3;               // token tiles per wave: Lp <= 192 -> 12 tiles over >= 4 waves
-  // Two heads of head_dim 6 are 36 features: two 16-wide tiles + 4.  The last four (head 1's v[2..5]) run on
-  // v_mfma_f32_4x4x1_16b_f32 (a 64-token group per wave instruction, lane = token, 72 k-steps of 8 cycles) instead of
-  // a third 16-wide tile that is three quarters padding: 25 % fewer matrix cycles in the projection.
-  constexpr bool REMF = HD == 6 && HPW == 2 && NCT == 3;
-  constexpr int NCTM = REMF ? 2 : NCT;  // 16-wide feature tiles on the 16x16x4 form
+  // Two heads of head_dim 6 are 36 features: two 16-wide tiles + 4 (head 1's v[2..5]).  A third tile would be three
+  // quarters padding; the four features are vector-ALU dot products instead (each lane holds 18 of its token's 72 x
+  // values as A operand anyway: 4 x 18 FMAs + two xor-shuffles per 16 tokens, like k_qkv_attention's two).  Round 3 ran
+  // them on v_mfma_f32_4x4x1_16b_f32 (lane = token), which needed every x row a second time in that layout (55 KB more
+  // L2 reads per workgroup, 72 registers): 100.4 -> 99.8 us at ECG B = 512 without it.
+  constexpr bool REMV = HD == 6 && HPW == 2 && NCT == 3;
+  constexpr int NCTM = REMV ? 2 : NCT;  // 16-wide feature tiles on the 16x16x4 form
   constexpr float T = 64.0f;  // scores (log2 domain) may sit this far from the reference before it is refreshed
   extern __shared__ __align__(16) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -655,7 +675,7 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
   const int Lp = KT * 32;
   // the LDS images have a COMPILE-TIME row stride (a wave owns QG q-tiles, a head two waves: Lp <= LS): every LDS address
   // below is one per-lane base + immediate offsets instead of multiplications by a run-time Lp
-  constexpr int LS = 64 * QG;
+  constexpr int LS = 64 * QG + 4;  // (+ 4: see k_qkv_attention)
   constexpr int RS = LS * (8 + 4 * KST);                       // floats per head region: V | K^T | Q^T
   float4* wl = reinterpret_cast<float4*>(lds + (size_t)HPW * RS);  // weight pack [NCT][S4][64] float4
   const int half = lane >> 5, l31 = lane & 31;
@@ -682,13 +702,6 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     float xr[MAXT][REM > 0 ? REM : 1];
 #pragma unroll
     for (int u = 0; u < MAXT; ++u) load_x(min(wave + u * NW, TT - 1), xa[u], xr[u]);
-    // ... and, for the four features on the 4x4x1 form (below), this lane's token row of the wave's 64-token group
-    float4 xq[REMF ? D / 4 : 1];
-    if constexpr (REMF) {
-      const float* xp = xb + (size_t)min(64 * wave + lane, L - 1) * D;
-#pragma unroll
-      for (int c = 0; c < D / 4; ++c) xq[c] = *reinterpret_cast<const float4*>(xp + 4 * c);
-    }
     {
       const float4* Wq = reinterpret_cast<const float4*>(awp) + (size_t)hg * NCT * S4 * 64;
       for (int i = threadIdx.x; i < NCT * S4 * 64; i += 64 * NW) wl[i] = Wq[i];
@@ -714,10 +727,46 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
     }
     __syncthreads();
     if constexpr (STAMP) st_t[2] = FFD_STAMP_T();
+    // columns n = 0 .. 3 of the pack's third tile for this lane's k subset (qq), from the staged pack
+    float4 wv4[REMV ? 4 : 1][REMV ? C16 : 1];
+    float2 wvr[REMV ? 4 : 1];
+    float bvv[REMV ? 4 : 1];
+    if constexpr (REMV) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+#pragma unroll
+        for (int j = 0; j < C16; ++j) wv4[f][j] = wl[(2 * S4 + j) * 64 + 16 * qq + f];
+        const float4 r4 = wl[(2 * S4 + S4 - 1) * 64 + 16 * qq + f];
+        wvr[f] = float2{r4.x, r4.y};
+        bvv[f] = abp[2 * 16 + f];
+      }
+    }
 #pragma unroll
     for (int it = 0; it < MAXT; ++it) {
       const int tt = wave + it * NW;
       if (tt >= TT) break;
+      if constexpr (REMV) {
+        float pv[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+          float p = 0.f;
+#pragma unroll
+          for (int j = 0; j < C16; ++j) {
+            p = fmaf(xa[it][j].x, wv4[f][j].x, p), p = fmaf(xa[it][j].y, wv4[f][j].y, p);
+            p = fmaf(xa[it][j].z, wv4[f][j].z, p), p = fmaf(xa[it][j].w, wv4[f][j].w, p);
+          }
+#pragma unroll
+          for (int i = 0; i < REM; ++i) p = fmaf(xr[it][i], i == 0 ? wvr[f].x : wvr[f].y, p);
+          p += __shfl_xor(p, 16);
+          p += __shfl_xor(p, 32);
+          pv[f] = p + bvv[f];
+        }
+        if (qq == 0) {  // head 1 of the workgroup, v[2 .. 5] of token 16 tt + n
+          float* vp = lds + RS + (16 * tt + n) * 8 + 2;
+          *reinterpret_cast<float2*>(vp) = float2{pv[0], pv[1]};
+          *reinterpret_cast<float2*>(vp + 2) = float2{pv[2], pv[3]};
+        }
+      }
       f32x4 acc[NCTM];
 #pragma unroll
       for (int ct = 0; ct < NCTM; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -756,40 +805,6 @@ __global__ __launch_bounds__(128 * HPW, 3) void k_qkv_attention_mh(
             vp[0] = o.x, vp[8] = o.y, vp[16] = o.z, vp[24] = o.w;
           }
         }
-      }
-    }
-    if constexpr (REMF) {
-      // features 32 .. 35 (head 1, v[2 .. 5]) for the 64-token group of this wave: lane l is token 64 g + l as the A
-      // operand (its x row, four k per load), feature l & 3 as the B operand (the pack's third tile, staged in LDS:
-      // lane (n, q) of k-chunk j holds k = 16 j + 4 q .. + 3 of feature n); D: lane (block, feature) holds the block's
-      // four tokens.  72 k-steps, k ascending (the 16x16x4 tiles sum k in another order: rounding-level, per feature).
-      const int g = wave;
-      if (64 * g < Lp) {
-        const int f = lane & 3;
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < D / 4; ++c) {
-          float4 w4;
-          if (c < 4 * C16) {
-            w4 = wl[(2 * S4 + (c >> 2)) * 64 + f + 16 * (c & 3)];
-          } else {  // the k remainder of the pack: lane (n, q) holds k = 16 C16 + 4 i + q in component i
-            const int i = c - 4 * C16;
-            const float4 w0 = wl[(2 * S4 + S4 - 1) * 64 + f], w1 = wl[(2 * S4 + S4 - 1) * 64 + f + 16];
-            const float4 w2 = wl[(2 * S4 + S4 - 1) * 64 + f + 32], w3 = wl[(2 * S4 + S4 - 1) * 64 + f + 48];
-            w4 = i == 0 ? float4{w0.x, w1.x, w2.x, w3.x} : i == 1 ? float4{w0.y, w1.y, w2.y, w3.y}
-                 : i == 2 ? float4{w0.z, w1.z, w2.z, w3.z} : float4{w0.w, w1.w, w2.w, w3.w};
-          }
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[c].x, w4.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[c].y, w4.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[c].z, w4.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_4x4x1f32(xq[c].w, w4.w, acc, 0, 0, 0);
-        }
-        const float bv = abp[2 * 16 + f];
-        float* reg_vs = lds + (size_t)RS;  // head 1 of the workgroup
-        const int t0 = 64 * g + 4 * (lane >> 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (t0 + i < Lp) reg_vs[(size_t)(t0 + i) * 8 + 2 + f] = acc[i] + bv;
       }
     }
   }
@@ -1042,7 +1057,7 @@ static hipError_t launch_mh_t(const float* x, const float* awp, const float* kt,
   constexpr int KST = (HD + 1) / 2;
   constexpr int S4 = (D + 15) / 16;
   const int KT = (L + 31) / 32;
-  const size_t lds = ((size_t)HPW * 64 * QG * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2) * sizeof(float);
+  const size_t lds = ((size_t)HPW * (64 * QG + 4) * (8 + 4 * KST) + (size_t)NCT * S4 * 256 + (size_t)HPW * 2) * sizeof(float);
   if (cdiv(2 * KT, 2 * HPW) > 3 || cdiv(KT, 2) > QG) return hipErrorInvalidValue;  // <= 3 token tiles, one q-group per wave
   if constexpr (D == 72 && HD == 6) {  // (the stamped twin exists for the headline shape only)
     if (stamp != nullptr) {
@@ -1081,7 +1096,7 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
                            unsigned long long* stamp = nullptr) {
   constexpr int KST = (HD + 1) / 2;
   const int KT = (L + 31) / 32;
-  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)2 * KT) * sizeof(float);
+  const size_t lds = ((size_t)(KT * 32 + 4) * (8 + 4 * KST) + (size_t)2 * KT) * sizeof(float);
   int nwaves = cdiv(KT, QG);
   if (nwaves > 4) nwaves = 4;
   if (cdiv(2 * KT, nwaves) > 8) return hipErrorInvalidValue;  // the projection loop is unrolled for <= 8 token tiles per wave
@@ -1106,7 +1121,7 @@ static hipError_t launch_split_t(const float* x, const float* awp, const float* 
   const int KT = (L + 31) / 32;
   if (cdiv(2 * KT, 4) > 8 || (kspl != 1 && kspl != 2 && kspl != 4)) return hipErrorInvalidValue;
   const int qsplit = cdiv(KT, 4 / kspl);
-  const size_t lds = ((size_t)KT * 32 * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP) + (size_t)2 * KT) * sizeof(float);
+  const size_t lds = ((size_t)(KT * 32 + 4) * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP) + (size_t)2 * KT) * sizeof(float);
   hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
                      vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl, (unsigned long long*)nullptr);
   return hipGetLastError();
