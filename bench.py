@@ -505,9 +505,9 @@ def main() -> None:
                 "ffd_kernel_timing_begin")
         run_steps(model, X, ts_c, n_total, step_size, 1, n_ev_steps, use_cache, stream, offset)
         N.check(lib.ffd_kernel_timing_end(ctx.handle), ctx.handle, "ffd_kernel_timing_end")
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r04_traffic.json")
         if not os.path.exists(tpath):
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         traffic_tab = json.load(open(tpath)) if os.path.exists(tpath) else {}
         key = f"{args.workload}:{B}" + (":cache" if use_cache else "")
         order = ([N.K_LSTM_REC, N.K_LSTM_GATES] if is_lstm else [N.K_FFN, N.K_ATTN, N.K_OUTPROJ]) + \
@@ -641,8 +641,9 @@ def main() -> None:
             out["other_workloads"] = [
                 measure_other(device, "syn512", 8192, 3, 1, True),
                 measure_other(device, "nasa_lstm", 8192, 20, 2, False),
-                measure_other(device, "nasa_lstm", 512, 20, 5, False),
-                measure_other(device, "nasa_lstm", 2048, 20, 3, False),  # the wavefront with every CU busy
+                measure_other(device, "nasa_lstm", 512, 200, 30, False),  # (0.25 s timed: a 20-step window right behind the
+                                                                          #  B = 8192 runs read 22 % low on one box)
+                measure_other(device, "nasa_lstm", 2048, 50, 5, False),  # the wavefront with every CU busy
             ]
             out["api_e2e"] = [api_e2e(device, B, "philox"), api_e2e(device, B, "torch")]
             out["api_e2e_over_value"] = out["api_e2e"][0]["samples_per_s"] / value

@@ -9,7 +9,7 @@ prof() {  # prof <name> <bench args...>: rocprofv3 --kernel-trace --stats of one
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 $R/bench.py --no-extras "$@" > $O/${name}_profiled.json 2>/dev/null
   cp $O/prof_$name/*/*kernel_stats.csv $O/${name}_kernel_stats.csv && rm -rf $O/prof_$name
 }
-rm -f $R/gpurun_out/traffic/r03_traffic.json
+rm -f $R/gpurun_out/traffic/r04_traffic.json
 python3 $R/bench.py --ablation > $O/bench_ecg_B512.json 2> $O/bench_ecg_B512.err
 echo "ecg done: $(python3 -c "import json; d=json.loads(open('$O/bench_ecg_B512.json').read().strip().splitlines()[-1]); print(d['value'], d['roofline']['frac'])")"
 prof ecg_B512
@@ -27,5 +27,10 @@ bash $R/tools/collect_traffic.sh ecg:512 --steps 20 --warmup 2 > $O/traffic_ecg.
 bash $R/tools/collect_traffic.sh syn512:2048 --workload syn512 --batch 2048 --steps 2 --warmup 1 > $O/traffic_syn.log 2>&1
 bash $R/tools/collect_traffic.sh nasa_lstm:8192 --workload nasa_lstm --batch 8192 --steps 2 --warmup 1 > $O/traffic_lstm8192.log 2>&1
 bash $R/tools/collect_traffic.sh nasa_lstm:512 --workload nasa_lstm --batch 512 --steps 5 --warmup 1 > $O/traffic_lstm512.log 2>&1
-cp $R/gpurun_out/traffic/r03_traffic.json $O/r03_traffic.json
+cp $R/gpurun_out/traffic/r04_traffic.json $O/r04_traffic.json
+python3 $R/tools/batch_sweep.py 2>/dev/null | grep '^{"B"' > $O/batch_sweep.txt
+python3 $R/tools/ffn_d_sweep.py 2>/dev/null | grep '^{' > $O/ffn_d_sweep.txt
+python3 $R/tools/attn_phases.py ecg 512 2>/dev/null > $O/attn_phases_ecg512.json
+python3 $R/tools/attn_phases.py syn512 2048 2>/dev/null > $O/attn_phases_syn2048.json
+python3 $R/tools/attn_phases.py ecg 512 0 2>/dev/null > $O/attn_phases_ecg512_pure.json
 ls -la $O

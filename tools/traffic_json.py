@@ -1,10 +1,10 @@
-"""Merge rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r03_traffic.json.
+"""Merge rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into profiles/r04_traffic.json.
 tools/traffic_json.py <key-prefix e.g. ecg:512> <fetch dir> <write dir> [out.json]
 HBM bytes per launch = 2 x FETCH_SIZE (gfx950 reports half of wide streaming reads, MI355X_MICROARCH.md section HBM)
 + WRITE_SIZE; both counters are in KB."""
 import collections, csv, glob, json, os, sys
 prefix, fdir, wdir = sys.argv[1:4]
-out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_traffic.json")
+out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r04_traffic.json")
 NAMES = [("k_ffn_rows", "k_ffn_rows"), ("k_lstm_wave", "k_lstm_wave"), ("k_ffn_ln", "k_ffn_ln"), ("k_qkv_attention", "k_qkv_attention"), ("k_linear_res_ln", "k_linear_res_ln"),
          ("k_embed", "k_embed"), ("k_unembed_mfma<72, true>", "k_unembed_mfma<sde>"), ("k_unembed_mfma<72, false>", "k_unembed"),
          ("k_lstm_mfma", "k_lstm_mfma"), ("k_lstm_layer", "k_lstm_layer"), ("k_linear_rm", "k_linear_rm"), ("k_sde_step", "k_sde_step"),
