@@ -43,8 +43,8 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 //                       -- a lane's operand depends on (lane & 3, lane >> 5) only: 8 distinct float4 per group.  Round 4:
 //                       stored COMPACTED, eight logical groups per 1 KiB piece ([logical group % 8][lane class = (lane & 3)
 //                       + 4 (lane >> 5)][4]), read with a broadcast ds_read_b128: the remainder columns cost an eighth
-//                       of the ring bytes and DMA pieces they used to (d_model 72: 19 pieces per chunk instead of 26;
-//                       d_model 60, with 7 remainder groups: 17 instead of 41, which is what lets it fit the LDS)
+//                       of the ring bytes and DMA pieces (d_model 60, with 7 remainder groups: 17 pieces per chunk
+//                       instead of 41, which is what lets it fit the LDS; d_model 72 keeps whole groups: ring_compact)
 //   last group          lanes 0..7: b1[32 p + 4 lane + j]
 constexpr __host__ __device__ int ring_ct(int D) { return D / 32; }
 constexpr __host__ __device__ int ring_ng(int D) { return (D % 32) / 4; }
@@ -58,7 +58,11 @@ constexpr __host__ __device__ int ring_kperm(int D, int s, int half) {
 constexpr __host__ __device__ int ring_nmain(int D) { return ring_nq1(D) + 4 * ring_ct(D); }   // full 1 KiB groups of a chunk
 constexpr __host__ __device__ int ring_nrem(int D) { return 4 * ring_ng(D); }                    // logical remainder groups
 constexpr __host__ __device__ int ring_nfc(int D) { return ring_nmain(D) + ring_nrem(D); }       // logical fragment groups of a chunk
-constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nmain(D) + cdiv(ring_nrem(D), 8) + 1; }  // 1 KiB pieces
+// d_model 72 keeps its remainder groups as full 1 KiB groups (the ring fits, and the compacted form measured 0.8 % slower
+// there in an A/B on one box: 425.3 -> 428-429.5 us per launch at ECG B = 512); every other d_model stores them compacted
+constexpr __host__ __device__ bool ring_compact(int D) { return D != 72; }
+constexpr __host__ __device__ int ring_nfull(int D) { return ring_compact(D) ? ring_nmain(D) : ring_nfc(D); }  // groups stored whole
+constexpr __host__ __device__ int ring_chunk_groups(int D) { return ring_nfull(D) + cdiv(ring_nfc(D) - ring_nfull(D), 8) + 1; }  // 1 KiB pieces
 // float offset (inside its chunk / slot) of what `lane` reads of logical group k, k < nmain full groups, then compacted ones
 constexpr __host__ __device__ int ring_frag_off(int nmain, int k, int lane) {
   return k < nmain ? k * 256 + lane * 4
@@ -83,6 +87,9 @@ __global__ void k_pack_ffn_ring(const float* __restrict__ W1, const float* __res
     } else if (g < NQ1 + 4 * CT) {
       const int idx = 4 * (g - NQ1) + j, r = idx / CT, ct = idx % CT;
       v = W2[(size_t)(32 * ct + (lane & 31)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
+    } else if (g < SG - 1 && !ring_compact(D)) {  // a whole group per logical remainder group
+      const int idx = 4 * (g - NQ1 - 4 * CT) + j, r = idx / NG, gq = idx % NG;
+      v = W2[(size_t)(32 * CT + 4 * gq + (lane & 3)) * F + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * half];
     } else if (g < SG - 1) {  // compacted remainder piece: [logical group % 8][lane class][4]
       const int t = (int)(o & 255), lc = (t >> 2) & 7, kr = (g - NQ1 - 4 * CT) * 8 + (t >> 5);
       if (kr < 4 * NG) {
@@ -119,7 +126,13 @@ __global__ void k_pack_oproj_ring(const float* __restrict__ Wo, float* __restric
         const int kcol = ring_kperm(D, s, half);
         if (kcol < D) v = Wo[(size_t)(32 * ct + (lane & 31)) * D + kcol];
       }
-    } else if (g < NPM + (NPR + 7) / 8) {  // compacted remainder piece: [logical group % 8][lane class][4]
+    } else if (!ring_compact(D) && g < NPM + NPR) {  // a whole group per logical remainder group
+      const int idx = 4 * (g - NPM) + j, s = idx / NG, gq = idx % NG;
+      if (s < KS2) {
+        const int kcol = ring_kperm(D, s, half);
+        if (kcol < D) v = Wo[(size_t)(32 * CT + 4 * gq + (lane & 3)) * D + kcol];
+      }
+    } else if (ring_compact(D) && g < NPM + (NPR + 7) / 8) {  // compacted remainder piece: [logical group % 8][lane class][4]
       const int t = o & 255, lc = (t >> 2) & 7, kr = (g - NPM) * 8 + (t >> 5);
       if (kr < NPR) {
         const int idx = 4 * kr + j, s = idx / NG, gq = idx % NG;
@@ -155,7 +168,7 @@ struct FfnRowsCfg {
   static constexpr int KS2 = ring_ks2(D);
   static constexpr int CT = ring_ct(D), NG = ring_ng(D), NQ1 = ring_nq1(D);
   static constexpr int SGC = ring_chunk_groups(D);           // 1 KiB pieces per chunk (the last one: bias)
-  static constexpr int NMAIN = ring_nmain(D);                // full groups of a chunk; the remainder groups after them are compacted
+  static constexpr int NMAIN = ring_nfull(D);                // groups of a chunk stored whole; those after them are compacted
   static constexpr int NFC = ring_nfc(D);                    // (logical) fragment groups of a chunk = ds_read_b128 per lane
   static constexpr int SLOT_G = CPS * SGC;
   static constexpr int SLOT_FLOATS = SLOT_G * 256;
@@ -172,7 +185,8 @@ struct FfnRowsCfg {
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
   // fused out-projection slot
   static constexpr int NPM = oproj_npm(D), NPR = oproj_npr(D), NFP = NPM + NPR;  // logical groups of the slot
-  static constexpr int NFPP = NPM + cdiv(NPR, 8);                                // its 1 KiB pieces
+  static constexpr int NPF = ring_compact(D) ? NPM : NFP;                        // its groups stored whole
+  static constexpr int NFPP = NPF + cdiv(NFP - NPF, 8);                          // its 1 KiB pieces
 };
 
 // b + residual + LayerNorm of the wave's 32 rows, in registers.  acc[ct][4 t + i] = Y^T[c = 32 ct + 8 t + 4 half + i][row m]
@@ -516,7 +530,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
           }
           if (j == 1) {  // request group K + PD (of the next slot, a chunk slot, once past the end)
             const int KP = K + PD;
-            if (KP < NFP) f[KP] = *reinterpret_cast<const float4*>(slot + ring_frag_off(NPM, KP, lane_i));
+            if (KP < NFP) f[KP] = *reinterpret_cast<const float4*>(slot + ring_frag_off(C::NPF, KP, lane_i));
             else f[KP] = *reinterpret_cast<const float4*>(nslot + ring_frag_off(C::NMAIN, KP - NFP, lane_i));
             if (K == NFP - 1) {
 #pragma unroll
