@@ -128,13 +128,15 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
 // needs no running maximum (its reference stays 0) and the key-tile loop skips the max reduction, the cross-half
 // exchange and the refresh test.  The caller zeroes nrm[0..1] before the barrier that precedes this call.
 template <int HD>
-__device__ __forceinline__ void head_norms(const float* kts, const float* qts, unsigned* nrm, int Lp, int LS, int tid, int nthreads) {
+__device__ __forceinline__ void head_norms(const float* kts, const float* qts, unsigned* nrm, int Lp, int LS, int tid, int nthreads,
+                                           int jq0 = 0, int jq1 = 1 << 30) {  // q rows [jq0, jq1) only
   float km = 0.f, qm = 0.f;
   for (int j = tid; j < Lp; j += nthreads) {
     float k2 = 0.f, q2 = 0.f;
+    const bool qon = j >= jq0 && j < jq1;
 #pragma unroll
     for (int e = 0; e < HD; ++e) {
-      const float kv = kts[e * LS + j], qv = qts[e * LS + j];
+      const float kv = kts[e * LS + j], qv = qon ? qts[e * LS + j] : 0.f;
       k2 = fmaf(kv, kv, k2), q2 = fmaf(qv, qv, q2);
     }
     km = fmaxf(km, k2), qm = fmaxf(qm, q2);
@@ -255,6 +257,16 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
     const float* xb = x + (size_t)b * L * D;
     const int TT = Lp >> 4;  // every row of the LDS images gets a (finite) value
+    // token tiles [tt0, tt1) this workgroup projects: all of them -- except on a pure cache hit in the split form, where
+    // K and V come from the tables and a workgroup needs q for ITS q-tiles only (the other workgroups of the head
+    // project theirs): 2 of 12 tiles at batch 1
+    int tt0 = 0, tt1 = TT;
+    if constexpr (SPLIT) {
+      if (q_only) {
+        const int qpw = nwaves / kspl;
+        tt0 = min(2 * qs * qpw, TT), tt1 = min(tt0 + 2 * qpw, TT);
+      }
+    }
     auto load_x = [&](int tt, float4(&xa)[C16 > 0 ? C16 : 1], float(&xr)[REM > 0 ? REM : 1]) {
       int tok = 16 * tt + n;
       if (tok >= L) tok = L - 1;  // padded tokens repeat the last row: finite values that are masked / never stored
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     float xr[PFX][REM > 0 ? REM : 1];
 #pragma unroll
     for (int u = 0; u < PFX; ++u)  // unconditional (tile index clamped): conditional loads would force vmcnt(0) waits
-      load_x(min(wave + u * nwaves, TT - 1), xa[u], xr[u]);
+      load_x(min(tt0 + wave + u * nwaves, TT - 1), xa[u], xr[u]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (STAMP) st_t[2] = FFD_STAMP_T();
     // Straight-line code (full unroll, forward exits only): a loop back-edge would make the compiler wait for
@@ -280,8 +292,8 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
 #pragma unroll
     for (int it = 0; it < MAXT; ++it) {
       const int u = it % PFX;
-      const int tt = wave + it * nwaves;
-      if (tt >= TT) break;
+      const int tt = tt0 + wave + it * nwaves;
+      if (tt >= tt1) break;
       f32x4 acc[NCTM];
 #pragma unroll
       for (int ct = 0; ct < NCTM; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -379,7 +391,16 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     }
   }
   __syncthreads();
-  head_norms<HD>(kts, qts, nrm, Lp, LS, threadIdx.x, blockDim.x);
+  {  // (q rows outside the projected token range were never written: they stay out of the bound)
+    int jq0 = 0, jq1 = Lp;
+    if constexpr (SPLIT) {
+      if (q_only) {
+        const int qpw = nwaves / kspl;
+        jq0 = min(32 * qs * qpw, Lp), jq1 = min(jq0 + 32 * qpw, Lp);
+      }
+    }
+    head_norms<HD>(kts, qts, nrm, Lp, LS, threadIdx.x, blockDim.x, jq0, jq1);
+  }
   // MIXED: batch element 0 publishes its recomputed rows (caching.py:326-328, cached_transformer.py:301-305)
   if (kt_out != nullptr && b == 0 && qs == 0) {
     for (int idx = threadIdx.x; idx < n_own * HD; idx += blockDim.x) {

@@ -33,4 +33,5 @@ python3 $R/tools/ffn_d_sweep.py 2>/dev/null | grep '^{' > $O/ffn_d_sweep.txt
 python3 $R/tools/attn_phases.py ecg 512 2>/dev/null > $O/attn_phases_ecg512.json
 python3 $R/tools/attn_phases.py syn512 2048 2>/dev/null > $O/attn_phases_syn2048.json
 python3 $R/tools/attn_phases.py ecg 512 0 2>/dev/null > $O/attn_phases_ecg512_pure.json
+python3 $R/bench.py --gpus 2 --rehearse-one-gpu --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_rehearse_2ranks_one_gpu.json 2> $O/bench_rehearse.err
 ls -la $O
