@@ -103,6 +103,7 @@ SIGNATURES = {
     "ffd_score_forward_ts": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "ffd_cache_configure": (C.c_int, [_P, C.POINTER(CacheCfg)]),
     "ffd_tune": (C.c_int, [C.c_char_p, C.c_int]),
+    "ffd_tune_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "ffd_bench_ffn": (C.c_int, [_P, C.c_int, C.c_int, _F, _P]),
     "ffd_probe_ffn_clock": (C.c_int, [_P, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int), _P]),

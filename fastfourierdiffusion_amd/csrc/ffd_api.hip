@@ -122,7 +122,7 @@ struct ffd_ctx {
       return ctx->fail(FFD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
   } while (0)
 
-static int g_fail_alloc_after = 0;  // tests: the n-th device allocation from now fails (ffd_tune "fail_alloc_after")
+static thread_local int g_fail_alloc_after = 0;  // tests: the n-th device allocation from now fails (ffd_tune "fail_alloc_after")
 
 static int dev_alloc(ffd_ctx* ctx, float** p, size_t nfloats) {
   *p = nullptr;
@@ -157,7 +157,7 @@ static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats, CapT* cap, CapT c
 }
 static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats) { return dev_regrow<int>(ctx, p, nfloats, nullptr, 0); }
 
-static int g_fuse_tail = 1;
+static thread_local int g_fuse_tail = 1;
 
 // HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
 struct Timed {
@@ -331,6 +331,29 @@ int ffd_tune(const char* key, int value) {
     g_attn_fused = value;
     return FFD_OK;
   }
+  return FFD_ERR_INVALID;
+}
+
+int ffd_tune_get(const char* key, int* value) {
+  if (!key || !value) return FFD_ERR_INVALID;
+  static const struct { const char* name; int* (*ptr)(); } tab[] = {
+#define K(name, var) {name, []() -> int* { return &var; }}
+      K("ffn_mb", g_ffn_mb_override), K("ffn_persist", g_ffn_persist), K("attn_small", g_attn_small),
+      K("embed_ldsx", g_embed_ldsx), K("embed_threads", g_embed_threads), K("ffn_split", g_ffn_split),
+      K("mid_path", g_mid_path), K("small_wgs", g_small_wgs), K("small_path", g_small_path), K("ffn_rows", g_ffn_rows),
+      K("ffn_rows_cps", g_ffn_rows_cps), K("ffn_rows_fuse", g_ffn_rows_fuse), K("rows_slices", g_rows_slices),
+      K("ffn_rows_nw", g_ffn_rows_nw), K("ffn_rem", g_ffn_rem), K("lstm_wave", g_lstm_wave),
+      K("lstm_wave_persist", g_lstm_wave_persist), K("lstm_wave_chunk", g_lstm_wave_chunk),
+      K("lstm_wave_per", g_lstm_wave_per), K("lstm_wave_fault", g_lstm_wave_fault),
+      K("lstm_wave_spin_ms", g_lstm_wave_spin_ms), K("fuse_tail", g_fuse_tail), K("attn_qg", g_attn_qg),
+      K("attn_hpw", g_attn_hpw), K("fail_alloc_after", g_fail_alloc_after), K("attn_fused", g_attn_fused),
+#undef K
+  };
+  for (const auto& e : tab)
+    if (!strcmp(key, e.name)) {
+      *value = *e.ptr();  // (the calling thread's copy: the knobs are thread_local)
+      return FFD_OK;
+    }
   return FFD_ERR_INVALID;
 }
 

@@ -178,7 +178,7 @@ static hipError_t launch_attn_mfma_t(const float* q, const float* k, const float
   return hipGetLastError();
 }
 
-int g_attn_qg = 0;  // 0 heuristic; 1/2/3 force the q-tile group size (ffd_tune "attn_qg")
+thread_local int g_attn_qg = 0;  // 0 heuristic; 1/2/3 force the q-tile group size (ffd_tune "attn_qg")
 
 template <int HD>
 static hipError_t launch_attn_mfma_hd(const float* q, const float* k, const float* v, const float* kt,

@@ -288,8 +288,8 @@ __global__ void k_embed(const float* __restrict__ X, const float* __restrict__ W
   }
 }
 
-int g_embed_ldsx = 1;  // ffd_tune "embed_ldsx": 0 = every lane loads its row's x itself
-int g_embed_threads = 262144;  // ffd_tune "embed_threads": threads the embed grid aims at (tools/probes/embed_sweep.py: 114 us at 256 k, 118 at 512 k, 137 at 128 k on the config-5 shape)
+thread_local int g_embed_ldsx = 1;  // ffd_tune "embed_ldsx": 0 = every lane loads its row's x itself
+thread_local int g_embed_threads = 262144;  // ffd_tune "embed_threads": threads the embed grid aims at (tools/probes/embed_sweep.py: 114 us at 256 k, 118 at 512 k, 137 at 128 k on the config-5 shape)
 
 hipError_t launch_embed(const float* X, const float* We, const float* be, const float* pos, const float* temb,
                         int temb_stride, float* h, int B, int L, int C, int D, hipStream_t s) {

@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   }
 }
 
-int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
+thread_local int g_ffn_persist = 1;      // 1: persistent grid for MB >= 4 (n > 1: n x the resident workgroups); 0: one workgroup per tile
 int num_cus() {
   static int n = 0;
   if (n == 0) {
@@ -430,8 +430,8 @@ int num_cus() {
   }
   return n;
 }
-int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
-int g_ffn_mb_override = 0;  // 0 = heuristic; 1 / 2 / 4 forces the tile height (ffd_tune "ffn_mb"; the 128-row MB = 8 instances -- never
+thread_local int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
+thread_local int g_ffn_mb_override = 0;  // 0 = heuristic; 1 / 2 / 4 forces the tile height (ffd_tune "ffn_mb"; the 128-row MB = 8 instances -- never
                             // selected, 400-656 B of scratch at d_model >= 48 -- were retired in round 4)
 
 template <int D>

@@ -703,10 +703,10 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
 }
 
 #ifndef FFD_ROWS_EXTRA_D
-int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
-int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
-int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
-int g_ffn_rows_fuse = 1;  // out-projection + LN1 inside the kernel (ffd_tune "ffn_rows_fuse"; two-chunk slots only)
+thread_local int g_ffn_rows = 1;     // 1: row-owning kernel for large M (ffd_tune "ffn_rows"); 0: k_ffn_ln; 2: at every M (tests)
+thread_local int g_ffn_rows_nw = 0;  // 0 = heuristic; 4 / 8 / 12 waves per workgroup
+thread_local int g_ffn_rows_cps = 0;  // 0 / 2: two chunks per ring slot; 1: one
+thread_local int g_ffn_rows_fuse = 1;  // out-projection + LN1 inside the kernel (ffd_tune "ffn_rows_fuse"; two-chunk slots only)
 
 // d_model values with an instance (round 4: 48, 60 -- the reference's class default, score_models.py:31 -- and 64 beside
 // 72; the compacted remainder groups are what fits d_model 60's seven of them into the ring)
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void k_rows_reduce_ln(const float* __restrict_
 }
 
 #ifndef FFD_ROWS_EXTRA_D
-int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuristic, -1 off, 2 / 4 / 8 / 16 forced (ffd_tune "rows_slices")
+thread_local int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuristic, -1 off, 2 / 4 / 8 / 16 forced (ffd_tune "rows_slices")
 
 // Mid-size M: (waves per workgroup, slices) of the sliced form, or false where another form is expected to be faster.
 // Estimate per launch (us, tools/ffn_rows_sweep.py at d_model 72, F 2048): out-projection slot + chunk slots at the

@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void k_ffn_ln_split(const float* __restrict
   }
 }
 
-int g_ffn_split = 0;  // ffd_tune "ffn_split": 1 = the bf16x3-split FFN (opt-in, not the reference's fp32 arithmetic)
+thread_local int g_ffn_split = 0;  // ffd_tune "ffn_split": 1 = the bf16x3-split FFN (opt-in, not the reference's fp32 arithmetic)
 
 bool ffn_split_supported(int D, int F) { return D % 4 == 0 && D <= 96 && F % 128 == 0; }
 

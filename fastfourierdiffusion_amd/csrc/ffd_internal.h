@@ -136,7 +136,7 @@ size_t ffn_ring_floats(int D, int F);
 hipError_t launch_pack_ffn_ring(const float* W1, const float* b1, const float* W2, float* out, int D, int F, hipStream_t s);
 hipError_t launch_ffn_rows(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                            unsigned long long* stamp = nullptr);
-extern int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_fuse;
+extern thread_local int g_ffn_rows, g_ffn_rows_nw, g_ffn_rows_cps, g_ffn_rows_fuse;
 // out-proj + LN1 + FFN + LN2 in one launch (the fused form of k_ffn_rows); Y must not alias attn / Rin
 bool ffn_rows_fused_selected(int M, int D, int F);
 size_t ffn_ring_oproj_floats(int D);
@@ -144,7 +144,7 @@ hipError_t launch_pack_oproj_ring(const float* Wo, float* out, int D, hipStream_
 hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const LayerWeights& w, float* Y, int M, int D,
                                  int F, hipStream_t s, unsigned long long* stamp = nullptr);
 // mid-size M: the fused kernel over tiles x slices of the hidden dimension + a reduce / LN2 launch
-extern int g_rows_slices;
+extern thread_local int g_rows_slices;
 bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out);
 size_t rows_slice_floats(int M, int D, int nslice);
 hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, const LayerWeights& w, float* P, float* Y,
@@ -158,23 +158,23 @@ hipError_t launch_oproj_ffn_small(const float* attn, const float* xres, const La
 // Mid-size M: the 64-row FFN main loop over F slices + the same reduce (ffd_small.hip); 0 = not this form
 int mid_path_splits(int M, int D, int F);
 hipError_t launch_ffn_mid(const float* x1, const LayerWeights& w, float* P, float* Y, int M, int D, int F, int NS, hipStream_t s);
-extern int g_mid_path;
-extern int g_small_path;
-extern int g_small_wgs;
+extern thread_local int g_mid_path;
+extern thread_local int g_small_path;
+extern thread_local int g_small_wgs;
 // Opt-in bf16x3-split FFN (ffd_tune "ffn_split"; ffd_ffn_split.hip)
-extern int g_ffn_split;
-extern int g_embed_threads;
-extern int g_embed_ldsx;
+extern thread_local int g_ffn_split;
+extern thread_local int g_embed_threads;
+extern thread_local int g_embed_ldsx;
 bool ffn_split_supported(int D, int F);
 size_t w1split_bytes(int D, int F);
 size_t w2split_bytes(int D, int F);
 hipError_t launch_pack_ffn_split(const float* W1, const float* W2, void* w1s, void* w2s, int D, int F, hipStream_t s);
 hipError_t launch_ffn_ln_split(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                                unsigned long long* stamp = nullptr);
-extern int g_ffn_mb_override;
-extern int g_ffn_rem;
-extern int g_ffn_persist;
-extern int g_attn_fused;
+extern thread_local int g_ffn_mb_override;
+extern thread_local int g_ffn_rem;
+extern thread_local int g_ffn_persist;
+extern thread_local int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
 size_t attn_pack_floats(int D, int H, int hpw, int q_only);
 hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
@@ -182,13 +182,13 @@ hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, i
 bool qkv_attention_supported(int D, int hd);
 int qkv_attention_hpw(int D, int hd, int L, int B);
 int qkv_attention_small_split(int B, int H, int L);
-extern int g_attn_small;
+extern thread_local int g_attn_small;
 int num_cus();  // compute units of the current device (256 on MI355X); ffd_ffn.hip
-extern int g_attn_hpw;
+extern thread_local int g_attn_hpw;
 hipError_t launch_qkv_attention(const float* x, const float* awp, int hpw, int q_only, const float* kt,
                                 const float* vt, float* kt_out, float* vt_out, float* out, int B, int L, int D, int hd,
                                 int n_own, hipStream_t s, unsigned long long* stamp = nullptr);
-extern int g_attn_qg;
+extern thread_local int g_attn_qg;
 
 // Head-major projection: columns [r*d, (r+1)*d) of Y = X Wp^T + b go to region out[r]
 // laid out (B, H, L, hd) -- each (sample, head) slice contiguous, the layout of the K/V tables.
@@ -209,7 +209,7 @@ hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B,
 // err: host-visible word that receives 1 + (unit index) when a wait on a progress word runs out of time
 bool lstm_wave_selected(int B, int D);
 int lstm_wave_max_batch(int L, int D);  // samples one k_lstm_wave launch takes (a 16-sample tile per CU, rows < 2^31 bytes); larger batches go in sub-batches
-extern int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk, g_lstm_wave_fault, g_lstm_wave_spin_ms;
+extern thread_local int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk, g_lstm_wave_fault, g_lstm_wave_spin_ms;
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
                             int B, int L, int D, int* prog, float* state, int* err, hipStream_t s);
 size_t lstm_wave_state_floats(int B, int D, int NL);

@@ -541,12 +541,12 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
 
 constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5 * 16 * (D + 2)) * 4; }
 
-int g_lstm_wave_persist = 1;  // 1: one launch, workgroups run their units in order (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
-int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
-int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
-int g_lstm_wave_fault = 0;    // tests: unit fault - 1 never publishes its progress (the waits on it must time out as an ERROR)
-int g_lstm_wave_spin_ms = 2000;  // time limit of one wait on a progress word (ffd_tune "lstm_wave_spin_ms")
-int g_lstm_wave = 1;  // 1 (or 2): the layer-wavefront kernel, the LSTM path at every batch; 0: the per-layer kernels k_linear_rm + k_lstm_layer (tests' cross-check)
+thread_local int g_lstm_wave_persist = 1;  // 1: one launch, workgroups run their units in order (ffd_tune "lstm_wave_persist"); 0: a launch per layer group
+thread_local int g_lstm_wave_per = 0;      // > 0: at most this many layers in flight (tests)
+thread_local int g_lstm_wave_chunk = 0;    // cell steps per unit where the (tile, layer) pairs outnumber the CUs: 0 by the pass count, 1 never, even n forced
+thread_local int g_lstm_wave_fault = 0;    // tests: unit fault - 1 never publishes its progress (the waits on it must time out as an ERROR)
+thread_local int g_lstm_wave_spin_ms = 2000;  // time limit of one wait on a progress word (ffd_tune "lstm_wave_spin_ms")
+thread_local int g_lstm_wave = 1;  // 1 (or 2): the layer-wavefront kernel, the LSTM path at every batch; 0: the per-layer kernels k_linear_rm + k_lstm_layer (tests' cross-check)
 
 // (batches past a 16-sample tile per CU go through the launcher in sub-batches of 16 CUs samples)
 // ... and so that a sub-batch's rows stay inside one raw-buffer resource (< 2^31 bytes; long sequences)

@@ -1148,7 +1148,7 @@ static hipError_t launch_split_t(const float* x, const float* awp, const float* 
   return hipGetLastError();
 }
 
-int g_attn_small = 1;  // 0 never, 1 by batch size, 2 / 4 force that many key pieces (ffd_tune "attn_small")
+thread_local int g_attn_small = 1;  // 0 never, 1 by batch size, 2 / 4 force that many key pieces (ffd_tune "attn_small")
 
 // Key pieces per q-tile of the small-batch split form, 0 when the one-workgroup-per-head(-pair) kernels run: the
 // split form projects a head once per q-split, which only pays while the chip is not full.
@@ -1192,7 +1192,7 @@ static hipError_t launch_dh(const float* x, const float* awp, int q_only, const 
   return launch_t<D, HD, 2, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, s, stamp);
 }
 
-int g_attn_fused = 1;  // 1: fused in-projection + attention where a kernel exists (ffd_tune "attn_fused")
+thread_local int g_attn_fused = 1;  // 1: fused in-projection + attention where a kernel exists (ffd_tune "attn_fused")
 
 // (d_model, head_dim) pairs with a fused kernel; anything else keeps the two-kernel path.
 bool qkv_attention_supported(int D, int hd) {
@@ -1201,7 +1201,7 @@ bool qkv_attention_supported(int D, int hd) {
          (D == 24 && hd == 3);
 }
 
-int g_attn_hpw = 0;  // 0 heuristic, 1 / 2 force heads per workgroup (ffd_tune "attn_hpw")
+thread_local int g_attn_hpw = 0;  // 0 heuristic, 1 / 2 force heads per workgroup (ffd_tune "attn_hpw")
 
 // heads per workgroup the fused kernel uses for this shape (the caller passes the matching weight pack)
 int qkv_attention_hpw(int D, int hd, int L, int B) {

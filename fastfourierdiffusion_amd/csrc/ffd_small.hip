@@ -423,8 +423,8 @@ __global__ __launch_bounds__(256) void k_ffn_reduce_ln(const float* __restrict__
   }
 }
 
-int g_small_wgs = 0;   // ffd_tune "small_wgs": most workgroups (row tiles x F splits) of the split pair; 0 = heuristic
-int g_small_path = 1;  // ffd_tune "small_path": 0 disables the split out-proj + FFN pair
+thread_local int g_small_wgs = 0;   // ffd_tune "small_wgs": most workgroups (row tiles x F splits) of the split pair; 0 = heuristic
+thread_local int g_small_path = 1;  // ffd_tune "small_path": 0 disables the split out-proj + FFN pair
 
 // F splits for M rows (0: use the large-M kernels).  The most splits (<= 16, F / (64 NS) chunks per wave in
 // {2, 4, 8, 16}: the kernel's instances) that keep the grid within 2.5 workgroups per CU; failing that, within 6
@@ -443,7 +443,7 @@ int small_path_splits(int M, int D, int F) {
   return 0;
 }
 
-int g_mid_path = 1;  // ffd_tune "mid_path": 0 off, 1 heuristic, 2 / 4 / 8 force that many F slices where the form applies
+thread_local int g_mid_path = 1;  // ffd_tune "mid_path": 0 off, 1 heuristic, 2 / 4 / 8 force that many F slices where the form applies
 
 // F slices of the 64-row form for M rows, 0 = not this form (checked after small_path_splits).  Model fitted to
 // tools/sweep_mid.py: a CU retires a 64-row tile of k_ffn_ln every ~73 us whether it hosts one workgroup or two, so

@@ -18,9 +18,9 @@
  *   - I/O buffers are caller-owned and only borrowed for the stream-ordered
  *     call; weights are copied (and re-packed) into context-owned HBM;
  *   - one context per device; a context is not thread-safe, distinct contexts
- *     are independent: the only process-wide state is the experiment knobs of
- *     ffd_tune (kernel choice / tiling, never results) and a per-device cache of
- *     FFT twiddle tables;
+ *     are independent: the only process-wide state is a per-device cache of FFT
+ *     twiddle tables (the experiment knobs of ffd_tune -- kernel choice / tiling,
+ *     never results -- are per calling thread);
  *   - tensors are dense row-major fp32: series X/score (B, L, C) with C
  *     innermost and L the Fourier / attention axis (score_models.py:87-90,
  *     fourier.py:12,24).
@@ -285,11 +285,13 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
                      int first_step, int n_run, uint64_t seed, uint64_t sample_offset, const float* z_inject,
                      int use_cache, int global_step0, void* stream);
 
-/* Process-wide tuning knobs for experiments and for the test suite's kernel variants (results stay within the
- * parity tolerance, only the kernel choice / tiling changes):
+/* Tuning knobs for experiments and for the test suite's kernel variants (results stay within the parity tolerance,
+ * only the kernel choice / tiling changes).  PER CALLING THREAD since round 4 (thread_local): a knob set on one thread
+ * selects kernels for the launches THAT thread makes and is invisible to every other thread, so two samplers on two
+ * threads cannot disturb each other; a thread starts from the defaults.  ffd_tune_get reads the calling thread's value.
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 4       rows/16 per workgroup of k_ffn_ln;
  *   "reset" (value ignored)                    every knob below back to its default;
- *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72): row-owning waves + CU-shared LDS weight ring
+ *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72 / 64 / 60 / 48): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
  *                                              every M where the small- / mid-batch forms are off (test suite);
  *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave);
@@ -331,6 +333,7 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "attn_qg" = 0 (heuristic) | 1 | 2 | 3      query tiles per wave;
  */
 int ffd_tune(const char* key, int value);
+int ffd_tune_get(const char* key, int* value);
 
 /* ---- introspection for benchmarks --------------------------------------- */
 

@@ -473,3 +473,44 @@ def test_isa_lint_clean_on_every_kernel_source():
     wave = {k: v for k, v in kernels(os.path.join(csrc, ".isa", "ffd_lstm.s")).items() if "k_lstm_waveILi72E" in k}
     assert wave and all(v == 0 for v in wave.values()), wave
 
+
+
+def test_tune_knobs_are_per_thread():
+    """ffd_tune's knobs are thread_local (round 4): a value set on one thread is neither seen nor overwritten by another,
+    a new thread starts from the defaults, and "reset" restores the calling thread's table only.  (No device needed.)"""
+    import ctypes as C
+    import threading
+
+    from fastfourierdiffusion_amd import _native as N
+
+    lib = N.lib()
+
+    def get(key):
+        v = C.c_int(-12345)
+        assert lib.ffd_tune_get(key, C.byref(v)) == 0, key
+        return v.value
+
+    assert lib.ffd_tune(b"reset", 0) == 0
+    defaults = {k: get(k) for k in (b"ffn_rows_nw", b"rows_slices", b"lstm_wave_spin_ms", b"attn_hpw", b"ffn_rows")}
+    assert defaults[b"lstm_wave_spin_ms"] == 2000 and defaults[b"ffn_rows"] == 1
+    assert lib.ffd_tune(b"ffn_rows_nw", 8) == 0 and lib.ffd_tune(b"rows_slices", 4) == 0
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        seen["start"] = {k: get(k) for k in defaults}           # a fresh thread: defaults, not the main thread's 8 / 4
+        assert lib.ffd_tune(b"ffn_rows_nw", 12) == 0 and lib.ffd_tune(b"attn_hpw", 1) == 0
+        go.set()
+        done.wait(10)
+        seen["end"] = {k: get(k) for k in defaults}             # untouched by the main thread's reset
+
+    t = threading.Thread(target=other)
+    t.start()
+    assert go.wait(10)
+    assert get(b"ffn_rows_nw") == 8 and get(b"rows_slices") == 4 and get(b"attn_hpw") == defaults[b"attn_hpw"]
+    assert lib.ffd_tune(b"reset", 0) == 0
+    assert {k: get(k) for k in defaults} == defaults
+    done.set()
+    t.join(10)
+    assert seen["start"] == defaults
+    assert seen["end"][b"ffn_rows_nw"] == 12 and seen["end"][b"attn_hpw"] == 1 and seen["end"][b"rows_slices"] == defaults[b"rows_slices"]
+    assert lib.ffd_tune_get(b"no_such_knob", C.byref(C.c_int())) != 0
