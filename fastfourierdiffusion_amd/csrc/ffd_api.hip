@@ -203,7 +203,7 @@ int ffd_tune(const char* key, int value) {
   if (!key) return FFD_ERR_INVALID;
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
-    g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
+    g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_rows_slices_fuse = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144,
     g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
     return FFD_OK;
@@ -267,6 +267,11 @@ int ffd_tune(const char* key, int value) {
   if (!strcmp(key, "rows_slices")) {  // sliced form of the fused kernel at mid-size M: 0 heuristic, -1 off, 2..32 slices forced
     if (value < -1 || value == 1 || value > 32) return FFD_ERR_INVALID;
     g_rows_slices = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "rows_slices_fuse")) {  // sliced form: 0 by estimate | 1 out-projection inside every unit | 2 k_linear_res_ln once in front
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_rows_slices_fuse = value;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_rows_nw")) {
@@ -341,7 +346,7 @@ int ffd_tune_get(const char* key, int* value) {
       K("ffn_mb", g_ffn_mb_override), K("ffn_persist", g_ffn_persist), K("attn_small", g_attn_small),
       K("embed_ldsx", g_embed_ldsx), K("embed_threads", g_embed_threads), K("ffn_split", g_ffn_split),
       K("mid_path", g_mid_path), K("small_wgs", g_small_wgs), K("small_path", g_small_path), K("ffn_rows", g_ffn_rows),
-      K("ffn_rows_cps", g_ffn_rows_cps), K("ffn_rows_fuse", g_ffn_rows_fuse), K("rows_slices", g_rows_slices),
+      K("ffn_rows_cps", g_ffn_rows_cps), K("ffn_rows_fuse", g_ffn_rows_fuse), K("rows_slices", g_rows_slices), K("rows_slices_fuse", g_rows_slices_fuse),
       K("ffn_rows_nw", g_ffn_rows_nw), K("ffn_rem", g_ffn_rem), K("lstm_wave", g_lstm_wave),
       K("lstm_wave_persist", g_lstm_wave_persist), K("lstm_wave_chunk", g_lstm_wave_chunk),
       K("lstm_wave_per", g_lstm_wave_per), K("lstm_wave_fault", g_lstm_wave_fault),
@@ -819,16 +824,22 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
         if (int rc = dev_regrow(ctx, &ctx->ffn_part, need, &ctx->ffn_part_floats, need)) return rc;
       }
       TIMED(FFD_K_FFN, launch_oproj_ffn_small(ctx->attn, cur, w, alt, ctx->ffn_part, cur, M, d, F, ns, s));
-    } else if (int snw = 0, sns = 0; !split_ffn && w.ring_op != nullptr && rows_slice_plan(M, d, F, &snw, &sns)) {
-      // mid-size M, d_model 72: the fused kernel below over tiles x slices of the hidden dimension (a unit per CU) and
-      // the reduce / LN2 launch (deterministic: the slices are added in order)
+    } else if (int snw = 0, sns = 0, sunf = 0; !split_ffn && w.ring_op != nullptr && rows_slice_plan(M, d, F, &snw, &sns, &sunf)) {
+      // mid-size M: the row-owning kernel over tiles x slices of the hidden dimension and the reduce / LN2 launch
+      // (deterministic: the slices are added in order) -- with the out-projection + LN1 inside every unit, or (where
+      // the units are short) as one k_linear_res_ln launch in front
       const size_t need = rows_slice_floats(M, d, sns);
       if (need > ctx->ffn_part_floats) {
         if (int rc = dev_regrow(ctx, &ctx->ffn_part, need, &ctx->ffn_part_floats, need)) return rc;
       }
-      TIMED(FFD_K_FFN, launch_oproj_ffn_rows_sliced(ctx->attn, cur, w, ctx->ffn_part, alt, M, d, F, snw, sns, s));
-      float* t = cur;
-      cur = alt, alt = t;
+      if (sunf) {
+        TIMED(FFD_K_OUTPROJ, launch_linear_res_ln(ctx->attn, pk.out_wp, w.out_b, cur, w.n1w, w.n1b, alt, M, d, s));
+        TIMED(FFD_K_FFN, launch_ffn_rows_sliced(alt, w, ctx->ffn_part, cur, M, d, F, snw, sns, s));
+      } else {
+        TIMED(FFD_K_FFN, launch_oproj_ffn_rows_sliced(ctx->attn, cur, w, ctx->ffn_part, alt, M, d, F, snw, sns, s));
+        float* t = cur;
+        cur = alt, alt = t;
+      }
     } else if (!split_ffn && !mid_path_splits(M, d, F) && w.ring_op != nullptr && ffn_rows_fused_selected(M, d, F)) {
       // large M, d_model 72: out-proj + LN1 + FFN + LN2 in one launch (x1 never leaves the CU); the output goes to the
       // other hidden buffer (rows are read and written by different waves of different tiles: no in-place form)
@@ -1400,9 +1411,11 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       else if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
         name = "k_oproj_ffn_split + k_ffn_reduce_ln", fl = 4.0 * M * d * F + 2.0 * M * d * d,
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
-      else if (int a_ = 0, b_ = 0; tr && rows_slice_plan((int)M, m.d_model, m.dim_feedforward, &a_, &b_))
-        name = "k_ffn_rows<oproj, sliced> + k_rows_reduce_ln", fl = 4.0 * M * d * F + b_ * 2.0 * M * d * d,
-        by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
+      else if (int a_ = 0, b_ = 0, u_ = 0; tr && rows_slice_plan((int)M, m.d_model, m.dim_feedforward, &a_, &b_, &u_)) {
+        if (u_) name = "k_ffn_rows<sliced> + k_rows_reduce_ln", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
+        else name = "k_ffn_rows<oproj, sliced> + k_rows_reduce_ln", fl = 4.0 * M * d * F + b_ * 2.0 * M * d * d,
+             by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
+      }
       else if (tr && mid_path_splits((int)M, m.d_model, m.dim_feedforward))
         name = "k_ffn_part", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d + 2.0 * d * F);
       else if (tr && ffn_rows_fused_selected((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
@@ -1419,9 +1432,11 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       }
       break;
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
-      if (int a_ = 0, b_ = 0; !g_ffn_split && tr && !small_path_splits((int)M, m.d_model, m.dim_feedforward) &&
-                               rows_slice_plan((int)M, m.d_model, m.dim_feedforward, &a_, &b_))
+      if (int a_ = 0, b_ = 0, u_ = 0; !g_ffn_split && tr && !small_path_splits((int)M, m.d_model, m.dim_feedforward) &&
+                                       rows_slice_plan((int)M, m.d_model, m.dim_feedforward, &a_, &b_, &u_)) {
+        if (u_) name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);
         break;
+      }
       if (tr && (g_ffn_split || (!small_path_splits((int)M, m.d_model, m.dim_feedforward) &&
                                  !(!mid_path_splits((int)M, m.d_model, m.dim_feedforward) &&
                                    ffn_rows_fused_selected((int)M, m.d_model, m.dim_feedforward)))))

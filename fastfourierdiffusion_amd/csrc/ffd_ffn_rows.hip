@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_ffn_rows(const float* __restrict
                                                              const float* __restrict__ gam1, const float* __restrict__ bet1,
                                                              float* __restrict__ Y, int M, int F, int nslice,
                                                              unsigned long long* stamp) {
-  static_assert(!SL || OP, "the sliced form recomputes the out-projection per slice");
+  // (SL without OP, round 4: X is x1 itself -- k_linear_res_ln ran once for all slices -- and slice 0 adds x1 + b2)
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): the record k_ffn_ln writes (8 x u64 per
   // workgroup), to memory nothing else reads
   using C = FfnRowsCfg<D, NW, CPS, NSLOT>;
@@ -763,16 +763,23 @@ thread_local int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuri
 // Mid-size M: (waves per workgroup, slices) of the sliced form, or false where another form is expected to be faster.
 // Estimate per launch (us, tools/ffn_rows_sweep.py at d_model 72, F 2048): out-projection slot + chunk slots at the
 // pace of NW / 4 waves per SIMD + launch / prologue / tile end, + the reduce launch; a unit per CU at most.
-bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
+// *unfused_out (round 4): 1 where the slices should NOT recompute the out-projection (k_linear_res_ln once in front, no
+// out-projection slot per unit: the better deal where the units are short, i.e. small M and many slices).
+thread_local int g_rows_slices_fuse = 0;  // 0 heuristic, 1 fused only, 2 unfused only (ffd_tune "rows_slices_fuse")
+bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out, int* unfused_out) {
   if (g_rows_slices < 0 || !g_ffn_rows || !g_ffn_rows_fuse || g_ffn_rows_cps == 1 || !ffn_rows_supported(D, F)) return false;
   const int nslots = F / 64;
   double best = 1e30;
-  int bnw = 0, bs = 0;
+  int bnw = 0, bs = 0, bunf = 0;
+  for (int unf = 0; unf <= 1; ++unf)
   for (int nw = 8; nw <= 12; nw += 4) {
+    if ((unf == 1 && (g_rows_slices_fuse == 1 || unfused_out == nullptr)) || (unf == 0 && g_rows_slices_fuse == 2 && unfused_out)) continue;
     if (g_ffn_rows_nw && g_ffn_rows_nw != nw) continue;
     const int tiles = cdiv(M, 32 * nw);
     // (measured at d_model 72; the matrix cycles of a slot go with d_model)
-    const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots * (D / 72.0), p_us = (nw == 12 ? 10.0 : 7.0) * (D / 72.0);
+    // p_us: what a unit of the fused form pays for its out-projection slot (slot + its barrier + LN1; fitted to the
+    // round-4 sweep of fused-only against unfused-only, B = 96 ... 768)
+    const double slot_us = (nw == 12 ? 392.0 : 271.0) / 32.0 * (F / 2048.0) * 32.0 / nslots * (D / 72.0), p_us = (nw == 12 ? 14.0 : 10.0) * (D / 72.0);
     const int smax = nslots < 16 ? nslots : 16;
     for (int sl = 2; sl <= smax; ++sl) {
       if (g_rows_slices > 0 && g_rows_slices != sl) continue;
@@ -780,8 +787,11 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
       const int g = num_cus() / sl < tiles ? num_cus() / sl : tiles;
       if (g < 1) continue;
       const int rounds = cdiv(tiles, g);
-      const double t = rounds * (p_us + cdiv(nslots, sl) * slot_us) + 15.0 + 6.0 + 1.2e-4 * M * (sl + 1) * D * 4 / 1000.0;
-      if (t < best) best = t, bnw = nw, bs = sl;
+      // (unfused: + one k_linear_res_ln launch, 21.6 us at 95 744 rows, and a launch boundary; no out-projection slot)
+      // (+ 5 us of handicap: within that the two forms measure alike, and the fused one is one launch fewer)
+      const double t = rounds * ((unf ? 0.0 : p_us) + cdiv(nslots, sl) * slot_us) + 15.0 + 6.0 +
+                       1.2e-4 * M * (sl + 1) * D * 4 / 1000.0 + (unf ? 5.0 + 8.0 + 0.15e-3 * M * (D / 72.0) : 0.0);
+      if (t < best) best = t, bnw = nw, bs = sl, bunf = unf;
     }
   }
   if (!bs) return false;
@@ -799,6 +809,7 @@ bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out) {
     if (best > 0.97 * alt) return false;
   }
   *nw_out = bnw, *nslice_out = bs;
+  if (unfused_out) *unfused_out = bunf;
   return true;
 }
 size_t rows_slice_floats(int M, int D, int nslice) { return (size_t)nslice * M * D; }
@@ -852,7 +863,15 @@ static hipError_t launch_rows_cfg(const RowsArgs& a, hipStream_t s) {
       return hipGetLastError();
     }
   }
-  if (a.fused || a.nslice > 0) return hipErrorInvalidValue;
+  if (a.fused) return hipErrorInvalidValue;
+  if (a.nslice > 0) {  // sliced form on x1 rows (k_linear_res_ln ran in front): no out-projection slot per unit
+    if constexpr (CPS == 2 && NSLOT == 3 && NW >= 8) {
+      if (gsl < 1 || a.nslice > a.F / 64) return hipErrorInvalidValue;
+      FFD_ROWS_LAUNCH(PRV, false, true);
+      return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+  }
   FFD_ROWS_LAUNCH(PRV, false, false);
 #undef FFD_ROWS_LAUNCH
 #undef FFD_ROWS_LAUNCH2
@@ -940,6 +959,22 @@ hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, con
   return hipGetLastError();
 }
 
+// The same slicing on x1 rows (k_linear_res_ln has run): Y = LN2(x1 + FFN(x1)); P holds nslice x M x D floats.
+hipError_t launch_ffn_rows_sliced(const float* X1, const LayerWeights& w, float* P, float* Y, int M, int D, int F, int nw,
+                                  int nslice, hipStream_t s) {
+  if (!ffn_rows_supported(D, F) || nslice < 2) return hipErrorInvalidValue;
+  RowsArgs a{X1, nullptr, &w, P, M, F, false, nullptr};
+  a.nslice = nslice;
+  const hipError_t e = launch_rows_any(a, D, s, nw);
+  if (e != hipSuccess) return e;
+  switch (D) {
+#define X(d) case d: hipLaunchKernelGGL(k_rows_reduce_ln<d>, dim3(cdiv(M, 8)), dim3(256), 0, s, P, nslice, M, w.n2w, w.n2b, Y); break;
+    X(72) X(64) X(60) X(48)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 #endif
 
 }  // namespace ffd

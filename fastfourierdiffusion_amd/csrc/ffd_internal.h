@@ -145,7 +145,10 @@ hipError_t launch_oproj_ffn_rows(const float* attn, const float* Rin, const Laye
                                  int F, hipStream_t s, unsigned long long* stamp = nullptr);
 // mid-size M: the fused kernel over tiles x slices of the hidden dimension + a reduce / LN2 launch
 extern thread_local int g_rows_slices;
-bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out);
+bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out, int* unfused_out = nullptr);
+extern thread_local int g_rows_slices_fuse;
+hipError_t launch_ffn_rows_sliced(const float* X1, const LayerWeights& w, float* P, float* Y, int M, int D, int F, int nw,
+                                  int nslice, hipStream_t s);
 size_t rows_slice_floats(int M, int D, int nslice);
 hipError_t launch_oproj_ffn_rows_sliced(const float* attn, const float* Rin, const LayerWeights& w, float* P, float* Y,
                                         int M, int D, int F, int nw, int nslice, hipStream_t s);

@@ -294,6 +294,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72 / 64 / 60 / 48): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
  *                                              every M where the small- / mid-batch forms are off (test suite);
+ *   "rows_slices_fuse" = 0 (by estimate) | 1 | 2 sliced form of k_ffn_rows: the out-projection + LN1 inside every unit (1) or as
+ *                                              one k_linear_res_ln launch in front of slices without that slot (2);
  *   "ffn_rows_nw" = 0 (heuristic) | 4 | 8 | 12 waves per workgroup of k_ffn_rows (a tile is 32 rows per wave);
  *   "ffn_rows_cps" = 0 | 2 | 1                 32-unit chunks per ring slot (= per barrier) of k_ffn_rows (default 2);
  *   "ffn_rows_fuse" = 1 | 0                    out-projection + residual + LN1 inside k_ffn_rows (one more ring slot per

@@ -1365,10 +1365,16 @@ def test_rows_sliced_form_agrees_with_the_other_forms(ffd, name, batches):
                 if -(-B * c["L"] // (32 * nw)) * S > 256:
                     continue
                 assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"rows_slices", S) == 0
+                assert lib.ffd_tune(b"rows_slices_fuse", 1) == 0  # the out-projection + LN1 inside every unit
                 a = m(batch_of(x, 0.4))
                 b = m(batch_of(x, 0.4))
                 assert torch.equal(a, b), (B, nw, S)
                 assert rel_err(a.cpu(), ref.cpu()) < 2e-6, (B, nw, S)
+                assert lib.ffd_tune(b"rows_slices_fuse", 2) == 0  # k_linear_res_ln once in front, slices without that slot
+                u = m(batch_of(x, 0.4))
+                assert torch.equal(u, m(batch_of(x, 0.4))), (B, nw, S)
+                assert rel_err(u.cpu(), ref.cpu()) < 2e-6, (B, nw, S)
+                assert lib.ffd_tune(b"rows_slices_fuse", 1) == 0
                 part = m(batch_of(x[: B // 2].contiguous(), 0.4))  # other tile / unit assignment
                 assert rel_err(part.cpu(), a[: B // 2].cpu()) < 2e-6, (B, nw, S)
         assert lib.ffd_tune(b"reset", 0) == 0
@@ -1393,12 +1399,14 @@ def test_rows_sliced_form_in_rounds(ffd):
         ref = m(batch_of(xb, 0.4))
         assert lib.ffd_tune(b"ffn_rows_nw", nw) == 0 and lib.ffd_tune(b"rows_slices", S) == 0
         assert -(-B * c["L"] // (32 * nw)) * S > 256  # more units than CUs: rounds
-        a = m(batch_of(xb, 0.4))
-        assert torch.equal(a, m(batch_of(xb, 0.4))), (B, nw, S)
-        assert rel_err(a.cpu(), ref.cpu()) < 2e-6, (B, nw, S)
-        nfit = (256 // S) * 32 * nw // c["L"]  # samples whose tiles x S units fit the chip in one round
-        one_round = m(batch_of(xb[:nfit].contiguous(), 0.4))
-        assert torch.equal(one_round, a[:nfit]), (B, nw, S)  # same slicing, same summation order: the same bits
+        for fuse in (1, 2):  # out-projection inside every unit | k_linear_res_ln once in front
+            assert lib.ffd_tune(b"rows_slices_fuse", fuse) == 0
+            a = m(batch_of(xb, 0.4))
+            assert torch.equal(a, m(batch_of(xb, 0.4))), (B, nw, S, fuse)
+            assert rel_err(a.cpu(), ref.cpu()) < 2e-6, (B, nw, S, fuse)
+            nfit = (256 // S) * 32 * nw // c["L"]  # samples whose tiles x S units fit the chip in one round
+            one_round = m(batch_of(xb[:nfit].contiguous(), 0.4))
+            assert torch.equal(one_round, a[:nfit]), (B, nw, S, fuse)  # same slicing, same summation order: the same bits
         assert lib.ffd_tune(b"reset", 0) == 0
     for B in (384, 768):
         xb = x[:B].contiguous()
