@@ -35,6 +35,7 @@ struct LayerPacked {
   float *w1s = nullptr, *w2s = nullptr;  // bf16x3 packs of the opt-in split FFN, made on first use
   float *aw_full = nullptr, *aw_q = nullptr;    // per-head packs of the fused in-projection + attention kernel
   float *aw_full2 = nullptr, *aw_q2 = nullptr;  // same, per pair of heads (two-head workgroups)
+  float* aw_kvq = nullptr;                      // per head, tile 0 = k | v, tile 1 = q (the split small-batch form)
 };
 
 __global__ void k_add_vec(const float* a, const float* b, float* o, int n) {
@@ -158,6 +159,7 @@ static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats, CapT* cap, CapT c
 static int dev_regrow(ffd_ctx* ctx, float** p, size_t nfloats) { return dev_regrow<int>(ctx, p, nfloats, nullptr, 0); }
 
 static thread_local int g_fuse_tail = 1;
+static thread_local int g_attn_kvq = 1;  // small-batch split attention on the kv | q pack (ffd_tune "attn_kvq")
 
 // HIP event pair around a launch of kernel class `cls` while ffd_kernel_timing_begin has its bit set
 struct Timed {
@@ -205,7 +207,7 @@ int ffd_tune(const char* key, int value) {
     g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_rows_slices_fuse = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144,
-    g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
+    g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_attn_kvq = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
@@ -331,6 +333,10 @@ int ffd_tune(const char* key, int value) {
     g_fail_alloc_after = value;
     return FFD_OK;
   }
+  if (!strcmp(key, "attn_kvq")) {  // small-batch split attention: q projected for own q-tiles only (kv | q pack) | 0: whole head
+    g_attn_kvq = value ? 1 : 0;
+    return FFD_OK;
+  }
   if (!strcmp(key, "attn_fused")) {
     if (value < 0 || value > 1) return FFD_ERR_INVALID;
     g_attn_fused = value;
@@ -351,7 +357,7 @@ int ffd_tune_get(const char* key, int* value) {
       K("lstm_wave_persist", g_lstm_wave_persist), K("lstm_wave_chunk", g_lstm_wave_chunk),
       K("lstm_wave_per", g_lstm_wave_per), K("lstm_wave_fault", g_lstm_wave_fault),
       K("lstm_wave_spin_ms", g_lstm_wave_spin_ms), K("fuse_tail", g_fuse_tail), K("attn_qg", g_attn_qg),
-      K("attn_hpw", g_attn_hpw), K("fail_alloc_after", g_fail_alloc_after), K("attn_fused", g_attn_fused),
+      K("attn_hpw", g_attn_hpw), K("attn_kvq", g_attn_kvq), K("fail_alloc_after", g_fail_alloc_after), K("attn_fused", g_attn_fused),
 #undef K
   };
   for (const auto& e : tab)
@@ -571,6 +577,8 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         if (qkv_attention_supported(d, d / m.n_head)) {
           if ((rc = dev_alloc(ctx, &pk.aw_full, attn_pack_floats(d, m.n_head, 1, 0)))) return rc;
           if ((rc = dev_alloc(ctx, &pk.aw_q, attn_pack_floats(d, m.n_head, 1, 1)))) return rc;
+          if (attn_kvq_supported(d / m.n_head))
+            if ((rc = dev_alloc(ctx, &pk.aw_kvq, attn_pack_floats(d, m.n_head, 1, 2)))) return rc;
           if (m.n_head % 2 == 0) {
             if ((rc = dev_alloc(ctx, &pk.aw_full2, attn_pack_floats(d, m.n_head, 2, 0)))) return rc;
             if ((rc = dev_alloc(ctx, &pk.aw_q2, attn_pack_floats(d, m.n_head, 2, 1)))) return rc;
@@ -594,6 +602,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         const float* in_b = W(pre + "self_attn.in_proj_bias");
         HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_full, d, m.n_head, 1, 0, s));
         HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_q, d, m.n_head, 1, 1, s));
+        if (pk.aw_kvq) HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_kvq, d, m.n_head, 1, 2, s));
         if (pk.aw_full2) {
           HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_full2, d, m.n_head, 2, 0, s));
           HIPCHECK(launch_pack_attn(in_w, in_b, pk.aw_q2, d, m.n_head, 2, 1, s));
@@ -798,8 +807,11 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       // in-projection + attention in one launch: q/k/v never leave the CU (ffd_qkvattn.hip); in MIXED batch
       // element 0's workgroups also publish their recomputed K/V rows (caching.py:326-328)
       const int hpw = pk.aw_full2 ? qkv_attention_hpw(d, hd, L, B) : 1;
-      const float* pack = hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
-      TIMED(FFD_K_ATTN, launch_qkv_attention(cur, pack, hpw, mode == PURE, tables ? kt : nullptr,
+      // (small batches, not a pure cache hit: the split form on the kv | q pack -- q projected for own q-tiles only)
+      const bool kvq = g_attn_kvq && pk.aw_kvq != nullptr && mode != PURE && qkv_attention_small_split(B, H, L) != 0;
+      const float* pack = kvq ? pk.aw_kvq
+                              : hpw == 2 ? (mode == PURE ? pk.aw_q2 : pk.aw_full2) : (mode == PURE ? pk.aw_q : pk.aw_full);
+      TIMED(FFD_K_ATTN, launch_qkv_attention(cur, pack, hpw, kvq ? 2 : mode == PURE, tables ? kt : nullptr,
                                              tables ? vt : nullptr, mode == MIXED ? kt : nullptr,
                                              mode == MIXED ? vt : nullptr, ctx->attn, B, L, d, hd, n_own, s));
     } else {

@@ -179,7 +179,8 @@ extern thread_local int g_ffn_rem;
 extern thread_local int g_ffn_persist;
 extern thread_local int g_attn_fused;
 // fused in-projection + attention (ffd_qkvattn.hip)
-size_t attn_pack_floats(int D, int H, int hpw, int q_only);
+size_t attn_pack_floats(int D, int H, int hpw, int q_only);  // q_only = pack mode: 0 q | k | v, 1 q only, 2 tile 0 = k | v, tile 1 = q
+bool attn_kvq_supported(int hd);                              // head dims with a mode-2 pack (the split small-batch form's)
 hipError_t launch_pack_attn(const float* in_w, const float* in_b, float* pack, int D, int H, int hpw, int q_only,
                             hipStream_t s);
 bool qkv_attention_supported(int D, int hd);

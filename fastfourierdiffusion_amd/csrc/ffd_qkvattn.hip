@@ -19,6 +19,8 @@
 // the rest from the shared tables (kt/vt != NULL); PURE (n_own = 0) runs with the q-only weight pack; in
 // MIXED the workgroups of batch element 0 also write their recomputed rows back to the tables
 // (caching.py:326-328).
+#include <type_traits>
+
 #include "ffd_internal.h"
 
 namespace ffd {
@@ -55,8 +57,11 @@ __global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict
   // one pack per head group (hpw consecutive heads): feature fi -> head hh = fi / fph, then (reg, e)
   const int steps4 = (D + 15) / 16;
   const int NG = H / hpw;
-  const int fph = q_only ? hd : 3 * hd;  // features per head
-  const int nf = hpw * fph;
+  // q_only is the pack MODE: 0 q | k | v of every head in feature order, 1 q only, 2 (one head per group) tile 0 = k | v,
+  // tile 1 = q -- the split small-batch form projects tile 1 for its own q-tiles' tokens only
+  const bool kvq = q_only == 2;
+  const int fph = q_only == 1 ? hd : 3 * hd;  // features per head
+  const int nf = kvq ? 32 : hpw * fph;
   const int total = NG * nct * steps4 * 64 * 4;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int i = idx & 3, lane = (idx >> 2) & 63;
@@ -71,9 +76,14 @@ __global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict
     else k = (4 * i < D - 16 * j) ? 16 * j + 4 * i + q : -1;
     float v = 0.f;
     if (fi < nf && k >= 0 && k < D) {
-      const int hh = fi / fph, f = fi - hh * fph;
-      const int reg = f / hd, e = f - reg * hd;
-      v = W[(size_t)(reg * D + (hg * hpw + hh) * hd + e) * D + k] * (reg == 0 ? qscale : 1.f);
+      int hh = fi / fph, f = fi - hh * fph;
+      int reg = f / hd, e = f - reg * hd;
+      bool on = true;
+      if (kvq) {  // tile 0: k[0 .. hd), v[0 .. hd); tile 1: q[0 .. hd)
+        hh = 0, on = n < (ct == 0 ? 2 * hd : hd) && ct < 2;
+        reg = ct == 0 ? (n < hd ? 1 : 2) : 0, e = ct == 0 ? (n < hd ? n : n - hd) : n;
+      }
+      if (on) v = W[(size_t)(reg * D + (hg * hpw + hh) * hd + e) * D + k] * (reg == 0 ? qscale : 1.f);
     }
     awp[idx] = v;
   }
@@ -83,15 +93,22 @@ __global__ void k_pack_attn(const float* __restrict__ W, const float* __restrict
     const int fi = 16 * ct + n;
     float v = 0.f;
     if (fi < nf) {
-      const int hh = fi / fph, f = fi - hh * fph;
-      const int reg = f / hd, e = f - reg * hd;
-      v = b[reg * D + (hg * hpw + hh) * hd + e] * (reg == 0 ? qscale : 1.f);
+      int hh = fi / fph, f = fi - hh * fph;
+      int reg = f / hd, e = f - reg * hd;
+      bool on = true;
+      if (kvq) {
+        hh = 0, on = n < (ct == 0 ? 2 * hd : hd) && ct < 2;
+        reg = ct == 0 ? (n < hd ? 1 : 2) : 0, e = ct == 0 ? (n < hd ? n : n - hd) : n;
+      }
+      if (on) v = b[reg * D + (hg * hpw + hh) * hd + e] * (reg == 0 ? qscale : 1.f);
     }
     abp[idx] = v;
   }
 }
 
-static int attn_nct(int hd, int hpw, int q_only) { return cdiv(hpw * (q_only ? hd : 3 * hd), 16); }
+static int attn_nct(int hd, int hpw, int q_only) { return q_only == 2 ? 2 : cdiv(hpw * (q_only ? hd : 3 * hd), 16); }
+// head dims for which the kv | q pack exists: a head's k and v fit one 16-wide tile and q | k | v need two anyway
+bool attn_kvq_supported(int hd) { return 2 * hd <= 16 && 3 * hd > 16; }
 
 size_t attn_pack_floats(int D, int H, int hpw, int q_only) {
   const int nct = attn_nct(D / H, hpw, q_only);
@@ -155,7 +172,9 @@ __device__ __forceinline__ void head_norms(const float* kts, const float* qts, u
 // projecting the whole head but attending only nwaves/kspl q-tiles, with the key range of a q-tile cut into `kspl`
 // pieces over the waves (flash-decoding).  The pieces (reference exponent, row sum, unnormalised output) meet in
 // LDS and are merged in piece order, so the result does not depend on timing.
-template <int D, int HD, int QG, int NCT, bool SPLIT = false, bool STAMP = false>
+// KVQ (split form with the kv | q pack, NCT = 2): tile 0 holds the head's k and v features, tile 1 its q features, and a
+// workgroup projects tile 1 only for the tokens of its own q-tiles -- the other q-tiles' workgroups project theirs.
+template <int D, int HD, int QG, int NCT, bool SPLIT = false, bool STAMP = false, bool KVQ = false>
 __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
@@ -250,8 +269,13 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     for (int ct = 0; ct < NCTM; ++ct) {
       bias[ct] = abp[ct * 16 + n];
       const int fi = 16 * ct + n;
-      const int reg = fi / HD, e = fi - reg * HD;
-      const int kind = q_only ? (fi < HD ? 0 : 3) : (reg > 2 ? 3 : reg);  // 0 q, 1 k, 2 v, 3 none
+      int reg = fi / HD, e = fi - reg * HD;
+      int kind = q_only ? (fi < HD ? 0 : 3) : (reg > 2 ? 3 : reg);  // 0 q, 1 k, 2 v, 3 none
+      if constexpr (KVQ) {
+        static_assert(!KVQ || (SPLIT && NCT == 2 && 2 * HD <= 16), "kv | q pack");
+        kind = ct == 0 ? (n < HD ? 1 : n < 2 * HD ? 2 : 3) : (n < HD ? 0 : 3);
+        e = ct == 0 ? (n < HD ? n : n - HD) : n;
+      }
       sv[ct] = kind == 2;
       sbase[ct] = kind == 3 ? -1 : kind == 0 ? LS * 8 + 2 * KST * LS + e * LS : kind == 1 ? LS * 8 + e * LS : e;
     }
@@ -261,11 +285,11 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
     // K and V come from the tables and a workgroup needs q for ITS q-tiles only (the other workgroups of the head
     // project theirs): 2 of 12 tiles at batch 1
     int tt0 = 0, tt1 = TT;
+    int ot0 = 0, ot1 = TT;  // token tiles of this workgroup's own q-tiles (KVQ: only they get tile 1 = q)
     if constexpr (SPLIT) {
-      if (q_only) {
-        const int qpw = nwaves / kspl;
-        tt0 = min(2 * qs * qpw, TT), tt1 = min(tt0 + 2 * qpw, TT);
-      }
+      const int qpw = nwaves / kspl;
+      ot0 = min(2 * qs * qpw, TT), ot1 = min(ot0 + 2 * qpw, TT);
+      if (q_only) tt0 = ot0, tt1 = ot1;
     }
     auto load_x = [&](int tt, float4(&xa)[C16 > 0 ? C16 : 1], float(&xr)[REM > 0 ? REM : 1]) {
       int tok = 16 * tt + n;
@@ -297,23 +321,45 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       f32x4 acc[NCTM];
 #pragma unroll
       for (int ct = 0; ct < NCTM; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool own = !KVQ || (tt >= ot0 && tt < ot1);  // (wave-uniform) the q tile of the kv | q pack: own tokens only
+      auto tile_mfmas = [&](auto CTC) {
+        constexpr int ct = decltype(CTC)::value;
 #pragma unroll
-      for (int j = 0; j < C16; ++j) {
-#pragma unroll
-        for (int ct = 0; ct < NCTM; ++ct) {
+        for (int j = 0; j < C16; ++j) {
           acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
           acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
           acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
           acc[ct] = mfma16(xa[u][j].w, wf[ct][j].w, acc[ct]);
         }
-      }
 #pragma unroll
-      for (int i = 0; i < REM; ++i) {
-#pragma unroll
-        for (int ct = 0; ct < NCTM; ++ct) {
+        for (int i = 0; i < REM; ++i) {
           const float4 w4 = wf[ct][S4 - 1];
           const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
           acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
+        }
+      };
+      if constexpr (KVQ) {
+        tile_mfmas(std::integral_constant<int, 0>{});
+        if (own) tile_mfmas(std::integral_constant<int, 1>{});
+      } else {
+#pragma unroll
+        for (int j = 0; j < C16; ++j) {
+#pragma unroll
+          for (int ct = 0; ct < NCTM; ++ct) {
+            acc[ct] = mfma16(xa[u][j].x, wf[ct][j].x, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].y, wf[ct][j].y, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].z, wf[ct][j].z, acc[ct]);
+            acc[ct] = mfma16(xa[u][j].w, wf[ct][j].w, acc[ct]);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < REM; ++i) {
+#pragma unroll
+          for (int ct = 0; ct < NCTM; ++ct) {
+            const float4 w4 = wf[ct][S4 - 1];
+            const float wv = i == 0 ? w4.x : i == 1 ? w4.y : i == 2 ? w4.z : w4.w;
+            acc[ct] = mfma16(xr[u][i], wv, acc[ct]);
+          }
         }
       }
       float p16 = 0.f, p17 = 0.f;
@@ -342,7 +388,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
       for (int ct = 0; ct < NCTM; ++ct) {
         const float4 o = float4{acc[ct][0] + bias[ct], acc[ct][1] + bias[ct], acc[ct][2] + bias[ct],
                                 acc[ct][3] + bias[ct]};
-        if (sbase[ct] >= 0) {
+        if (sbase[ct] >= 0 && (ct == 0 || own)) {
           if (!sv[ct]) {
             *reinterpret_cast<float4*>(lds + sbase[ct] + t0) = o;
           } else {
@@ -394,7 +440,7 @@ __global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
   {  // (q rows outside the projected token range were never written: they stay out of the bound)
     int jq0 = 0, jq1 = Lp;
     if constexpr (SPLIT) {
-      if (q_only) {
+      if (q_only || KVQ) {
         const int qpw = nwaves / kspl;
         jq0 = min(32 * qs * qpw, Lp), jq1 = min(jq0 + 32 * qpw, Lp);
       }
@@ -1135,7 +1181,7 @@ static hipError_t launch_t(const float* x, const float* awp, const float* kt, co
 }
 
 // small batches: 4 waves per workgroup, 4 / kspl q-tiles per workgroup, the key range of each cut into kspl pieces
-template <int D, int HD, int NCT>
+template <int D, int HD, int NCT, bool KVQ = false>
 static hipError_t launch_split_t(const float* x, const float* awp, const float* kt, const float* vt, float* kt_out,
                                  float* vt_out, float* out, int B, int L, int n_own, int q_only, int kspl, hipStream_t s) {
   constexpr int KST = (HD + 1) / 2, HP = (HD + 1) / 2;
@@ -1143,7 +1189,7 @@ static hipError_t launch_split_t(const float* x, const float* awp, const float* 
   if (cdiv(2 * KT, 4) > 8 || (kspl != 1 && kspl != 2 && kspl != 4)) return hipErrorInvalidValue;
   const int qsplit = cdiv(KT, 4 / kspl);
   const size_t lds = ((size_t)(KT * 32 + 4) * (8 + 4 * KST) + (size_t)4 * 32 * (2 + 2 * HP) + (size_t)2 * KT) * sizeof(float);
-  hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
+  hipLaunchKernelGGL((k_qkv_attention<D, HD, 1, NCT, true, false, KVQ>), dim3(B * (D / HD) * qsplit), dim3(256), lds, s, x, awp, kt,
                      vt, kt_out, vt_out, out, B, L, n_own, q_only, qsplit, kspl, (unsigned long long*)nullptr);
   return hipGetLastError();
 }
@@ -1169,9 +1215,15 @@ static hipError_t launch_dh(const float* x, const float* awp, int q_only, const 
                             unsigned long long* stamp) {
   constexpr int NCTF = (3 * HD + 15) / 16;
   const int QT = (L + 31) / 32;
-  if (const int kspl = stamp ? 0 : qkv_attention_small_split(B, D / HD, L))
+  if (const int kspl = stamp ? 0 : qkv_attention_small_split(B, D / HD, L)) {
+    if constexpr (2 * HD <= 16 && 3 * HD > 16) {  // (q_only == 2: the caller handed over the kv | q pack)
+      if (q_only == 2) return launch_split_t<D, HD, 2, true>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, kspl, s);
+    }
+    if (q_only == 2) return hipErrorInvalidValue;
     return q_only ? launch_split_t<D, HD, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, kspl, s)
                   : launch_split_t<D, HD, NCTF>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 0, kspl, s);
+  }
+  if (q_only == 2) return hipErrorInvalidValue;  // the kv | q pack is the split form's only
   if (q_only) {
     if (stamp != nullptr) return hipErrorInvalidValue;
     if (QT == 1) return launch_t<D, HD, 1, 1>(x, awp, kt, vt, kt_out, vt_out, out, B, L, n_own, 1, s);

@@ -331,6 +331,8 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  *                                              the rounds come out whole, 1: layers walked whole, n: forced);
  *   "fuse_tail" = 1 | 0                        unembedding inside the SDE-step kernel of ffd_sample_batch (no FreSca);
  *   "attn_fused" = 1 | 0                       in-projection + attention in one kernel (k_qkv_attention*);
+ *   "attn_kvq" = 1 | 0                         small-batch split attention: tile 0 = k | v, tile 1 = q, q projected for a
+ *                                              workgroup's own q-tiles only (head_dim 6 / 8) | the whole head;
  *   "attn_hpw" = 0 (heuristic) | 1 | 2         heads per workgroup of that kernel;
  *   "attn_qg" = 0 (heuristic) | 1 | 2 | 3      query tiles per wave;
  */
