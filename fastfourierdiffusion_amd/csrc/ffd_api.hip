@@ -1068,6 +1068,15 @@ int ffd_fresca(const float* in, float* out, float* work, int B, int L, int C, fl
   return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
 }
 
+int ffd_fresca2d(const float* in, float* out, float* work, int B, int H, int W, int C, float low_scale,
+                 float high_scale, double cutoff_ratio, int strategy, void* stream) {
+  if (!in || !out || !work || in == out || B < 1 || H < 1 || W < 1 || C < 1) return FFD_ERR_INVALID;
+  if (strategy != FFD_FRESCA_SPATIAL && strategy != FFD_FRESCA_ENERGY) return FFD_ERR_INVALID;  // fresca.py:103 ValueError
+  if (!fresca2d_supported(H, W)) return FFD_ERR_UNSUPPORTED;
+  hipError_t e = launch_fresca2d(in, out, work, B, H, W, C, low_scale, high_scale, cutoff_ratio, strategy, (hipStream_t)stream);
+  return e == hipSuccess ? FFD_OK : (e == hipErrorInvalidValue ? FFD_ERR_UNSUPPORTED : FFD_ERR_HIP);
+}
+
 int ffd_fresca_enable(ffd_ctx* ctx, const ffd_fresca_cfg* cfg) {
   if (!ctx) return FFD_ERR_INVALID;
   if (!cfg) return ctx->fail(FFD_ERR_INVALID, "null fresca config");

@@ -1003,4 +1003,184 @@ hipError_t launch_spectral_density(const float* xf, float* out, int B, int L, in
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// FreSca, 4-D branch (fresca.py:184-213): x (B, H, W, C) -> irfft2( (l*low + h*high) (.) rfft2(x) ) over (H, W), ortho,
+// low = [sqrt(kh^2 + kw^2) <= Rc] on the raw bin indices (fresca.py:73-81).  Not on the sampling path (scores are 3-D):
+// a cold path, built for the completeness of fdiff.utils.fresca -- separable direct DFT sums in LDS, one (sample,
+// channel) image per workgroup, fp64 accumulation with fp32 intermediates, H, W <= 256 and H W <= 4096.
+//   k_fresca2d_fwd : X = rfft2(x) -> spec (complex), |X| -> mag            (per image)
+//   k_fresca2d_cut : energy strategy: spec_mean = mean_{b,c} |X|; Rc = first R in 0..int(min(H, nW) / 2) with
+//                    sum(spec_mean [dist <= R]) >= r0 * sum(spec_mean) (fresca.py:89-101), else 0; fixed summation order
+//   k_fresca2d_inv : scale, complex inverse DFT along H, c2r along W (imaginary parts of the kw = 0 and Nyquist columns
+//                    are ignored exactly as a c2r transform ignores them)
+// ---------------------------------------------------------------------------
+constexpr int F2D_MAX_HW = 4096, F2D_MAX_DIM = 256, F2D_MAX_SPEC = F2D_MAX_HW / 2 + F2D_MAX_DIM;
+
+__device__ __forceinline__ void f2d_tables(double2* twH, double2* twW, int H, int W) {
+  for (int r = threadIdx.x; r < H; r += blockDim.x) {
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)H, &sn, &cs);
+    twH[r] = make_double2(cs, sn);
+  }
+  for (int r = threadIdx.x; r < W; r += blockDim.x) {
+    double sn, cs;
+    sincospi(2.0 * (double)r / (double)W, &sn, &cs);
+    twW[r] = make_double2(cs, sn);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fresca2d_fwd(const float* __restrict__ in, float2* __restrict__ spec,
+                                                      float* __restrict__ mag, int H, int W, int C) {
+  __shared__ float img[F2D_MAX_HW];
+  __shared__ float2 T[F2D_MAX_SPEC];
+  __shared__ double2 twH[F2D_MAX_DIM], twW[F2D_MAX_DIM];
+  const int nW = W / 2 + 1;
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+  f2d_tables(twH, twW, H, W);
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) img[i] = in[((size_t)b * H * W + i) * C + c];
+  __syncthreads();
+  const double sw = 1.0 / sqrt((double)W), sh = 1.0 / sqrt((double)H);
+  for (int i = threadIdx.x; i < H * nW; i += blockDim.x) {  // rfft along W
+    const int h = i / nW, kw = i - h * nW;
+    double re = 0.0, im = 0.0;
+    int r = 0;
+    for (int w = 0; w < W; ++w) {
+      const double v = (double)img[h * W + w];
+      re += v * twW[r].x, im -= v * twW[r].y;
+      r += kw;
+      r -= r >= W ? W : 0;
+    }
+    T[i] = make_float2((float)(re * sw), (float)(im * sw));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * nW; i += blockDim.x) {  // complex DFT along H
+    const int kh = i / nW, kw = i - kh * nW;
+    double re = 0.0, im = 0.0;
+    int r = 0;
+    for (int h = 0; h < H; ++h) {
+      const double a = (double)T[h * nW + kw].x, bb = (double)T[h * nW + kw].y;
+      re += a * twH[r].x + bb * twH[r].y, im += bb * twH[r].x - a * twH[r].y;
+      r += kh;
+      r -= r >= H ? H : 0;
+    }
+    const float2 X = make_float2((float)(re * sh), (float)(im * sh));
+    spec[(size_t)blockIdx.x * H * nW + i] = X;
+    mag[(size_t)blockIdx.x * H * nW + i] = sqrtf(fmaf(X.x, X.x, X.y * X.y));
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fresca2d_cut(const float* __restrict__ mag, float* __restrict__ rc_out, int nimg,
+                                                      int H, int nW, float cutoff_ratio) {
+  __shared__ float sm[F2D_MAX_SPEC];
+  __shared__ float energy[F2D_MAX_DIM];
+  __shared__ float etot_s;
+  const int P = H * nW;
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float acc = 0.f;
+    for (int i = 0; i < nimg; ++i) acc += mag[(size_t)i * P + p];
+    sm[p] = acc / (float)nimg;  // mean over batch and channels (fresca.py:191)
+  }
+  __syncthreads();
+  const int rmax = min(H, nW) / 2;  // range(int(min(H, W) / 2) + 1)
+  if ((int)threadIdx.x <= rmax) {
+    double e = 0.0;
+    const float R = (float)threadIdx.x;
+    for (int p = 0; p < P; ++p) {
+      const int kh = p / nW, kw = p - kh * nW;
+      if (sqrtf((float)(kh * kh + kw * kw)) <= R) e += (double)sm[p];
+    }
+    energy[threadIdx.x] = (float)e;
+  }
+  if (threadIdx.x == 255) {
+    double e = 0.0;
+    for (int p = 0; p < P; ++p) e += (double)sm[p];
+    etot_s = (float)e;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float thr = cutoff_ratio * etot_s;
+    int rc = 0;
+    for (int R = 0; R <= rmax; ++R)
+      if (energy[R] >= thr) {
+        rc = R;
+        break;
+      }
+    *rc_out = (float)rc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_fresca2d_inv(const float2* __restrict__ spec, float* __restrict__ out,
+                                                      const float* __restrict__ rc_dev, float rc_host, float low,
+                                                      float high, int H, int W, int C) {
+  __shared__ float2 Xs[F2D_MAX_SPEC];
+  __shared__ float2 Z[F2D_MAX_SPEC];
+  __shared__ double2 twH[F2D_MAX_DIM], twW[F2D_MAX_DIM];
+  const int nW = W / 2 + 1;
+  const int b = blockIdx.x / C, c = blockIdx.x - b * C;
+  const float rc = rc_dev ? *rc_dev : rc_host;
+  f2d_tables(twH, twW, H, W);
+  for (int i = threadIdx.x; i < H * nW; i += blockDim.x) {
+    const int kh = i / nW, kw = i - kh * nW;
+    const float f = sqrtf((float)(kh * kh + kw * kw)) <= rc ? low : high;  // low*low_mask*X + high*high_mask*X
+    const float2 v = spec[(size_t)blockIdx.x * H * nW + i];
+    Xs[i] = make_float2(f * v.x, f * v.y);
+  }
+  __syncthreads();
+  const double sw = 1.0 / sqrt((double)W), sh = 1.0 / sqrt((double)H);
+  for (int i = threadIdx.x; i < H * nW; i += blockDim.x) {  // inverse complex DFT along H
+    const int h = i / nW, kw = i - h * nW;
+    double re = 0.0, im = 0.0;
+    int r = 0;
+    for (int kh = 0; kh < H; ++kh) {
+      const double a = (double)Xs[kh * nW + kw].x, bb = (double)Xs[kh * nW + kw].y;
+      re += a * twH[r].x - bb * twH[r].y, im += bb * twH[r].x + a * twH[r].y;
+      r += h;
+      r -= r >= H ? H : 0;
+    }
+    Z[i] = make_float2((float)(re * sh), (float)(im * sh));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) {  // c2r along W
+    const int h = i / W, w = i - h * W;
+    double acc = 0.0;
+    int r = 0;
+    for (int kw = 0; kw < nW; ++kw) {
+      const double a = (double)Z[h * nW + kw].x, bb = (double)Z[h * nW + kw].y;
+      const double wgt = (kw == 0 || 2 * kw == W) ? 1.0 : 2.0;
+      acc += wgt * (a * twW[r].x - bb * twW[r].y);
+      r += w;
+      r -= r >= W ? W : 0;
+    }
+    out[((size_t)b * H * W + i) * C + c] = (float)(acc * sw);
+  }
+}
+
+bool fresca2d_supported(int H, int W) {
+  return H >= 1 && W >= 1 && H <= F2D_MAX_DIM && W <= F2D_MAX_DIM && H * W <= F2D_MAX_HW;
+}
+size_t fresca2d_work_floats(int B, int H, int W, int C) { return (size_t)3 * B * C * H * (W / 2 + 1) + 4; }
+
+// work: fresca2d_work_floats(B, H, W, C) floats, 8-byte aligned
+hipError_t launch_fresca2d(const float* in, float* out, float* work, int B, int H, int W, int C, float low, float high,
+                           double cutoff_ratio, int strategy, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  if (C < 1 || !fresca2d_supported(H, W)) return hipErrorInvalidValue;
+  const int nW = W / 2 + 1, nimg = B * C;
+  float* rc = work;
+  float2* spec = reinterpret_cast<float2*>(work + 4);
+  float* mag = work + 4 + (size_t)2 * nimg * H * nW;
+  hipLaunchKernelGGL(k_fresca2d_fwd, dim3(nimg), dim3(256), 0, s, in, spec, mag, H, W, C);
+  const float* rc_dev = nullptr;
+  float rc_host = 0.f;
+  if (strategy == 1) {
+    hipLaunchKernelGGL(k_fresca2d_cut, dim3(1), dim3(256), 0, s, mag, rc, nimg, H, nW, (float)cutoff_ratio);
+    rc_dev = rc;
+  } else {  // spatial (fresca.py:84-86): Rc = r0 * min(H / 2, nW / 2), compared with the fp32 distances
+    rc_host = (float)(cutoff_ratio * fmin((double)H / 2.0, (double)nW / 2.0));
+  }
+  hipLaunchKernelGGL(k_fresca2d_inv, dim3(nimg), dim3(256), 0, s, spec, out, rc_dev, rc_host, low, high, H, W, C);
+  return hipGetLastError();
+}
+
+
 }  // namespace ffd

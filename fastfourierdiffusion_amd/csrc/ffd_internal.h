@@ -230,5 +230,10 @@ hipError_t launch_weighted_sum(const float* hist, const float* w_host, float* ou
 // FreSca spectral scaling of a (B,L,C) score; work: B*(L/2+1) + 1 floats; strategy 0 spatial, 1 energy
 hipError_t launch_fresca(const float* in, float* out, float* work, int B, int L, int C, float low, float high,
                          double cutoff_ratio, int strategy, hipStream_t s);
+// the 4-D (B, H, W, C) branch (rfft2 / irfft2 over H, W); work: fresca2d_work_floats floats
+bool fresca2d_supported(int H, int W);
+size_t fresca2d_work_floats(int B, int H, int W, int C);
+hipError_t launch_fresca2d(const float* in, float* out, float* work, int B, int H, int W, int C, float low, float high,
+                           double cutoff_ratio, int strategy, hipStream_t s);
 
 }  // namespace ffd

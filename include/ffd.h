@@ -205,6 +205,15 @@ enum { FFD_FRESCA_SPATIAL = 0, FFD_FRESCA_ENERGY = 1 };
 int ffd_fresca(const float* in, float* out, float* work, int B, int L, int C, float low_scale, float high_scale,
                double cutoff_ratio, int strategy, void* stream);
 
+/* The 4-D branch of frequency_scale (fresca.py:184-213): in / out (B, H, W, C), rfft2 / irfft2 over (H, W), ortho;
+ * low-pass mask [sqrt(kh^2 + kw^2) <= Rc] on the raw bin indices of the (H, W/2+1) half spectrum (fresca.py:73-81);
+ * "spatial": Rc = cutoff_ratio * min(H/2, (W/2+1)/2); "energy": the first integer radius R in 0..int(min(H, W/2+1)/2)
+ * whose disc holds cutoff_ratio of the batch-and-channel mean |X| (fresca.py:89-101), 0 if none does.  Not on the
+ * sampling path (scores are 3-D); H, W <= 256 and H*W <= 4096, else FFD_ERR_UNSUPPORTED.
+ * `work` = 3*B*C*H*(W/2+1) + 4 floats of scratch (8-byte aligned).  Context-free; in != out. */
+int ffd_fresca2d(const float* in, float* out, float* work, int B, int H, int W, int C, float low_scale,
+                 float high_scale, double cutoff_ratio, int strategy, void* stream);
+
 /* DiffusionSampler(use_fresca=True, ...) (sampler.py:21-26,79-93): apply FreSca to every score
  * inside ffd_sample_batch, with the reference's time-dependent high scale
  * h(t) = (1 - t/num_steps)*(h-1) + 1 for h > 1 (fresca.py:247-257; num_steps <= 0: static h). */

@@ -103,6 +103,17 @@ FRESCA_CASES = [
     ("syn_energy", 512, 8, 2, 77, 1.1, 1.4, 0.9, "energy", None, None),
     ("identity", 50, 3, 2, 78, 1.0, 1.0, 0.5, "energy", None, None),
 ]
+# the 4-D branch of frequency_scale (fresca.py:184-213): (name, H, W, C, B, seed, low, high, ratio, strategy)
+FRESCA2D_CASES = [
+    ("img_energy", 16, 16, 3, 4, 91, 1.0, 1.5, 0.5, "energy"),
+    ("img_spatial", 16, 12, 2, 3, 92, 0.8, 1.3, 0.5, "spatial"),
+    ("odd_energy", 9, 15, 1, 2, 93, 1.2, 0.7, 0.3, "energy"),
+    ("wide_spatial", 8, 64, 4, 2, 94, 1.0, 1.5, 0.25, "spatial"),
+    ("tall_energy", 48, 10, 2, 2, 95, 0.9, 2.0, 0.8, "energy"),
+    ("full_energy_never", 6, 6, 2, 2, 96, 0.5, 1.5, 1.0, "energy"),  # no disc holds all the energy: Rc stays 0
+    ("max_size", 64, 64, 1, 1, 97, 1.1, 1.4, 0.6, "energy"),
+    ("identity2d", 8, 8, 2, 2, 98, 1.0, 1.0, 0.5, "energy"),
+]
 FRESCA_DEFAULT = dict(low_scale=1.0, high_scale=1.5, cutoff_ratio=0.5, cutoff_strategy="energy")  # benchmark_cache.py:63-68
 
 # (K, R, L, steps)

@@ -211,6 +211,58 @@ def fresca(score: Tensor, low_scale: float = 1.0, high_scale: float = 1.0, cutof
     return torch.from_numpy(out.astype(np.float32))
 
 
+def _cdft_mats(n: int):
+    """Full complex DFT matrix of size n, ortho: (cos, -sin)(2 pi k m / n) / sqrt(n), fp64, exact integer phase reduction."""
+    km = (np.arange(n)[:, None] * np.arange(n)[None, :]) % n
+    ang = 2.0 * np.pi * km / n
+    return np.cos(ang) / np.sqrt(n), -np.sin(ang) / np.sqrt(n)
+
+
+def fresca2d(x: Tensor, low_scale: float = 1.0, high_scale: float = 1.0, cutoff_ratio: float = 0.5,
+             cutoff_strategy: str = "spatial") -> Tensor:
+    """frequency_scale, 4-D branch (fresca.py:184-213) with create_frequency_masks' 2-D case (fresca.py:66-107):
+    rfft2 / irfft2 over (H, W) restated as explicit fp64 DFT sums -- rfft along W, complex DFT along H; back: complex
+    inverse along H, then the c2r sum along W, which uses the real part of the kw = 0 (and Nyquist) column only."""
+    if low_scale == 1.0 and high_scale == 1.0:
+        return x
+    B, H, W, C = x.shape
+    nw = W // 2 + 1
+    cr, ci = _dft_mats(W)  # (nw, W)
+    hr, hi = _cdft_mats(H)  # (H, H)
+    xd = x.detach().to(torch.float64).numpy()
+    tr = np.einsum("kw,bhwc->bhkc", cr, xd)
+    ti = np.einsum("kw,bhwc->bhkc", ci, xd)
+    re = np.einsum("gh,bhkc->bgkc", hr, tr) - np.einsum("gh,bhkc->bgkc", hi, ti)
+    im = np.einsum("gh,bhkc->bgkc", hr, ti) + np.einsum("gh,bhkc->bgkc", hi, tr)
+    kx, ky = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(nw, dtype=torch.float32), indexing="ij")
+    k_dist = torch.sqrt(kx ** 2 + ky ** 2)  # fresca.py:73-81: raw bin indices, fp32
+    if cutoff_strategy == "spatial":
+        rc = cutoff_ratio * min(H / 2, nw / 2)  # fresca.py:84-86
+    elif cutoff_strategy == "energy":
+        spec = torch.from_numpy(np.sqrt(re * re + im * im).astype(np.float32)).mean(dim=(0, 3))  # fresca.py:191
+        etot = torch.abs(spec).sum()
+        rc = 0
+        for R in range(int(min(H, nw) / 2) + 1):  # fresca.py:95-101
+            energy = (torch.abs(spec) * (k_dist <= R).float()).sum()
+            if energy >= cutoff_ratio * etot:
+                rc = R
+                break
+    else:
+        raise ValueError(f"Unknown cutoff_strategy: {cutoff_strategy}")
+    low = (k_dist <= rc).float().numpy()
+    f = (np.float32(low_scale) * low + np.float32(high_scale) * (1.0 - low)).astype(np.float64)[None, :, :, None]
+    re, im = re * f, im * f
+    # inverse along H: conj(DFT) = (hr, -hi)
+    zr = np.einsum("hg,bgkc->bhkc", hr, re) + np.einsum("hg,bgkc->bhkc", hi, im)
+    zi = np.einsum("hg,bgkc->bhkc", hr, im) - np.einsum("hg,bgkc->bhkc", hi, re)
+    w = np.full(nw, 2.0)
+    w[0] = 1.0
+    if W % 2 == 0:
+        w[-1] = 1.0
+    out = np.einsum("kw,bhkc->bhwc", cr * w[:, None], zr) + np.einsum("kw,bhkc->bhwc", ci * w[:, None], zi)
+    return torch.from_numpy(out.astype(np.float32))
+
+
 # --------------------------------------------------------------------------
 # FreqCa helpers + spectral density          (src/fdiff/utils/fourier.py)
 # --------------------------------------------------------------------------

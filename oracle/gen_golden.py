@@ -230,10 +230,25 @@ def gen_round4(ns) -> None:
     np.savez_compressed(os.path.join(OUT, "g13_round4.npz"), **g)
 
 
+def gen_fresca2d(ns) -> None:
+    """G14: the 4-D (batch, H, W, channels) branch of frequency_scale (fresca.py:184-213)."""
+    from fdiff.utils.fresca import frequency_scale
+    g = {}
+    for (name, H, W, C, B, seed, lo, hi, ratio, strat) in cases.FRESCA2D_CASES:
+        x = torch.from_numpy(next(synthetic.noise_stream((B, H * W, C), 1, seed))).reshape(B, H, W, C)
+        y = frequency_scale(x, low_scale=lo, high_scale=hi, cutoff_ratio=ratio, cutoff_strategy=strat)
+        g[name] = y.numpy().copy()
+        print(name, tuple(y.shape), float(y.abs().max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "g14_fresca2d.npz"), **g)
+
+
 def main() -> None:
     os.makedirs(OUT, exist_ok=True)
     ns = import_reference()
     torch.set_num_threads(8)
+    if "--only-fresca2d" in sys.argv:  # just G14
+        gen_fresca2d(ns)
+        return
     if "--only-round4" in sys.argv:  # just G13
         gen_round4(ns)
         return
@@ -357,6 +372,7 @@ def main() -> None:
                                   timestep=tstep, num_steps=nsteps)
         g[name] = y.numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g6_fresca.npz"), **g)
+    gen_fresca2d(ns)
 
     # ---- G9: gate schedule ------------------------------------------------
     g = {}

@@ -157,6 +157,40 @@ def test_fresca_full_batch_properties(ffd):
         frequency_scale(x, 1.0, 1.5, 0.5, "radial")
 
 
+@pytest.mark.parametrize("case", cases.FRESCA2D_CASES, ids=lambda c: c[0])
+def test_fresca2d_golden(ffd, golden, case):
+    """frequency_scale on (batch, H, W, channels) (fresca.py:184-213): rfft2 -> radial mask on the bin indices -> irfft2."""
+    from fastfourierdiffusion_amd.utils.fresca import frequency_scale
+
+    name, H, W, C, B, seed, lo, hi, ratio, strat = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, H * W, C), 1, seed))).reshape(B, H, W, C).cuda()
+    y = frequency_scale(x, low_scale=lo, high_scale=hi, cutoff_ratio=ratio, cutoff_strategy=strat)
+    assert rel_err(y.cpu(), golden["g14_fresca2d"][name]) < TOL_OP
+    if lo == 1.0 and hi == 1.0:
+        assert y is x
+
+
+def test_fresca2d_properties_and_limits(ffd):
+    """l = h = s is a pure scaling; against the oracle at shapes the goldens do not hold (odd H, W = 1, a single row);
+    shapes past the kernel's LDS image are NotImplementedError, 5-D input the reference's ValueError (fresca.py:215)."""
+    from fastfourierdiffusion_amd.utils.fresca import frequency_scale
+
+    x = torch.randn(3, 20, 28, 2, device="cuda")
+    y = frequency_scale(x, low_scale=0.6, high_scale=0.6, cutoff_ratio=0.5, cutoff_strategy="energy")
+    assert torch.allclose(y, 0.6 * x, atol=2e-6)
+    for shape in ((2, 7, 11, 3), (2, 5, 1, 2), (1, 1, 32, 1), (2, 256, 16, 1), (1, 13, 256, 1)):
+        x = torch.randn(*shape)
+        for strat, ratio in (("spatial", 0.4), ("energy", 0.55)):
+            got = frequency_scale(x.cuda(), 0.9, 1.4, ratio, strat)
+            assert rel_err(got.cpu(), O.fresca2d(x, 0.9, 1.4, ratio, strat)) < TOL_OP, (shape, strat)
+    with pytest.raises(NotImplementedError):
+        frequency_scale(torch.randn(1, 128, 64, 1, device="cuda"), 1.0, 1.5)
+    with pytest.raises(NotImplementedError):
+        frequency_scale(torch.randn(1, 2, 300, 1, device="cuda"), 1.0, 1.5)
+    with pytest.raises(ValueError):
+        frequency_scale(torch.randn(1, 2, 3, 4, 5, device="cuda"), 1.0, 1.5)
+
+
 # ---------------------------------------------------------------- SDE ------
 @pytest.mark.parametrize("c", cases.STEP_CASES, ids=lambda c: c["name"])
 def test_step_golden(ffd, golden, c):

@@ -127,6 +127,15 @@ def test_fresca_golden(golden, case):
     assert rel_err(y, golden["g6_fresca"][name]) < TOL_KERNEL
 
 
+@pytest.mark.parametrize("case", cases.FRESCA2D_CASES, ids=lambda c: c[0])
+def test_fresca2d_golden(golden, case):
+    """The 4-D (batch, H, W, channels) branch of frequency_scale (fresca.py:184-213) against the unmodified reference."""
+    name, H, W, C, B, seed, lo, hi, ratio, strat = case
+    x = torch.from_numpy(next(synthetic.noise_stream((B, H * W, C), 1, seed))).reshape(B, H, W, C)
+    y = O.fresca2d(x, lo, hi, ratio, strat)
+    assert rel_err(y, golden["g14_fresca2d"][name]) < TOL_KERNEL
+
+
 _FAST_TRAJ = [c for c in cases.TRAJ_CASES if c["N"] * (c["d"] // 24) <= 400]
 _SLOW_TRAJ = [c for c in cases.TRAJ_CASES if c not in _FAST_TRAJ]
 
