@@ -152,7 +152,7 @@ hipError_t launch_time_embed(const float* ts, float t_imm, int n, const float* W
 // where its stores alone reach 6.1 (tools/probes/embed_sweep.py with the loads removed).  Instead the wave fetches the
 // (<= 64) contiguous floats of x its 64 lanes' rows need with ONE dword load, parks them in LDS and every lane reads
 // its row from there.  Slices are padded to whole waves so that the cooperating lanes share (slice, first row).
-template <bool XVEC, bool LDSX>
+template <bool XVEC, bool LDSX, bool TS>
 __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, const float* __restrict__ We,
                                                    const float* __restrict__ be, const float* __restrict__ pos,
                                                    const float* __restrict__ temb, int temb_stride,
@@ -219,7 +219,10 @@ __global__ __launch_bounds__(256) void k_embed_reg(const float* __restrict__ X, 
     for (int c = 0; c < 8; ++c)
       if (c < C) v.x = fmaf(xv[c], w[c].x, v.x), v.y = fmaf(xv[c], w[c].y, v.y), v.z = fmaf(xv[c], w[c].z, v.z), v.w = fmaf(xv[c], w[c].w, v.w);
     if (pos) v.x += p.x, v.y += p.y, v.z += p.z, v.w += p.w;
-    const float4 t = temb_stride ? *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j) : t0;
+    // (TS at compile time: as `temb_stride ? *p : t0` hipcc selected between the two ADDRESSES -- t0 parked in scratch,
+    //  32 B per lane, and a flat load per stored float4 even where the batch shares one time embedding)
+    float4 t = t0;
+    if constexpr (TS) t = *reinterpret_cast<const float4*>(temb + (size_t)b * temb_stride + j);
     if (active) *reinterpret_cast<float4*>(h + ((size_t)b * L + l) * D + j) = float4{v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w};
   };
   int b = (int)slice;
@@ -309,8 +312,13 @@ hipError_t launch_embed(const float* X, const float* We, const float* be, const 
     if (nslices > B) nslices = B;
     const unsigned blocks = (unsigned)(((size_t)nslices * LJP + 255) / 256);
     const bool xvec = (C == 4 || C == 8) && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(We)) & 15) == 0;
-#define FFD_EMBED(xv, lx) \
-  hipLaunchKernelGGL((k_embed_reg<xv, lx>), dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices)
+#define FFD_EMBED(xv, lx)                                                                                              \
+  do {                                                                                                                 \
+    if (temb_stride)                                                                                                   \
+      hipLaunchKernelGGL((k_embed_reg<xv, lx, true>), dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices); \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_embed_reg<xv, lx, false>), dim3(blocks), dim3(256), 0, s, X, We, be, pos, temb, temb_stride, h, B, L, C, D, nslices); \
+  } while (0)
     if (xvec && ldsx) FFD_EMBED(true, true);
     else if (xvec) FFD_EMBED(true, false);
     else if (ldsx) FFD_EMBED(false, true);
@@ -421,15 +429,14 @@ __device__ __forceinline__ void load_normals(const float* z, size_t i0, int n, u
     return;
   }
   uint64_t g0 = elem_offset + i0;
-  float a[4], b[4];
+  float a[4], b[4] = {0.f, 0.f, 0.f, 0.f};
   normal4(g0 >> 2, seed, step, a);
-  int sh = (int)(g0 & 3);
+  const int sh = (int)(g0 & 3);
   if (sh) normal4((g0 >> 2) + 1, seed, step, b);
+  // zz[j] = (a | b)[sh + j] as selects on static indices (indexed by sh the two arrays lived in scratch: 48 B per lane)
+  const float c[7] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2]};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int q = sh + j;
-    zz[j] = (q < 4) ? a[q & 3] : b[q & 3];
-  }
+  for (int j = 0; j < 4; ++j) zz[j] = sh == 0 ? c[j] : sh == 1 ? c[j + 1] : sh == 2 ? c[j + 2] : c[j + 3];
 }
 
 // ---------------------------------------------------------------------------

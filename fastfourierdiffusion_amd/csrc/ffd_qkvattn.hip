@@ -175,7 +175,7 @@ __device__ __forceinline__ void head_norms(const float* kts, const float* qts, u
 // KVQ (split form with the kv | q pack, NCT = 2): tile 0 holds the head's k and v features, tile 1 its q features, and a
 // workgroup projects tile 1 only for the tokens of its own q-tiles -- the other q-tiles' workgroups project theirs.
 template <int D, int HD, int QG, int NCT, bool SPLIT = false, bool STAMP = false, bool KVQ = false>
-__global__ __launch_bounds__(256, (QG <= 2 ? 4 : 3)) void k_qkv_attention(
+__global__ __launch_bounds__(256, (SPLIT && NCT >= 2 ? 2 : QG <= 2 ? 4 : 3)) void k_qkv_attention(
     const float* __restrict__ x, const float* __restrict__ awp, const float* __restrict__ kt,
     const float* __restrict__ vt, float* __restrict__ kt_out, float* __restrict__ vt_out, float* __restrict__ out,
     int B, int L, int n_own, int q_only, int qsplit, int kspl, unsigned long long* __restrict__ stamp) {
