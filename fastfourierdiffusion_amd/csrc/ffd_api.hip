@@ -204,15 +204,20 @@ extern "C" {
 int ffd_tune(const char* key, int value) {
   if (!key) return FFD_ERR_INVALID;
   if (!strcmp(key, "reset")) {  // every knob back to its default (the test suite calls this after each test)
-    g_ffn_mb_override = 0, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
+    g_ffn_mb_override = 0, g_ffn_height = 1, g_ffn_persist = 1, g_ffn_rem = 1, g_ffn_split = 0, g_ffn_rows = 1, g_ffn_rows_nw = 0,
     g_ffn_rows_cps = 0, g_ffn_rows_fuse = 1, g_rows_slices = 0, g_rows_slices_fuse = 0, g_mid_path = 1, g_small_path = 1, g_small_wgs = 0, g_attn_small = 1, g_attn_fused = 1,
     g_attn_hpw = 0, g_attn_qg = 0, g_embed_ldsx = 1, g_embed_threads = 262144,
     g_lstm_wave = 1, g_lstm_wave_persist = 1, g_lstm_wave_per = 0, g_lstm_wave_chunk = 0, g_fuse_tail = 1, g_attn_kvq = 1, g_fail_alloc_after = 0, g_lstm_wave_fault = 0, g_lstm_wave_spin_ms = 2000;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_mb")) {
-    if (value != 0 && value != 1 && value != 2 && value != 4) return FFD_ERR_INVALID;
+    if (value < 0 || value > 4) return FFD_ERR_INVALID;
     g_ffn_mb_override = value;
+    return FFD_OK;
+  }
+  if (!strcmp(key, "ffn_height")) {  // 32- / 48-row k_ffn_ln tiles where the 16-row tiles are 1.4 - 3 per CU: 0 off | 1 one launch | 2 behind k_linear_res_ln
+    if (value < 0 || value > 2) return FFD_ERR_INVALID;
+    g_ffn_height = value;
     return FFD_OK;
   }
   if (!strcmp(key, "ffn_persist")) {  // 0: one workgroup per tile; n >= 1: persistent grid of n x the resident workgroups
@@ -349,7 +354,7 @@ int ffd_tune_get(const char* key, int* value) {
   if (!key || !value) return FFD_ERR_INVALID;
   static const struct { const char* name; int* (*ptr)(); } tab[] = {
 #define K(name, var) {name, []() -> int* { return &var; }}
-      K("ffn_mb", g_ffn_mb_override), K("ffn_persist", g_ffn_persist), K("attn_small", g_attn_small),
+      K("ffn_mb", g_ffn_mb_override), K("ffn_height", g_ffn_height), K("ffn_persist", g_ffn_persist), K("attn_small", g_attn_small),
       K("embed_ldsx", g_embed_ldsx), K("embed_threads", g_embed_threads), K("ffn_split", g_ffn_split),
       K("mid_path", g_mid_path), K("small_wgs", g_small_wgs), K("small_path", g_small_path), K("ffn_rows", g_ffn_rows),
       K("ffn_rows_cps", g_ffn_rows_cps), K("ffn_rows_fuse", g_ffn_rows_fuse), K("rows_slices", g_rows_slices), K("rows_slices_fuse", g_rows_slices_fuse),
@@ -829,7 +834,10 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       ctx->layers[i].w1s = pkm.w1s;
       ctx->layers[i].w2s = pkm.w2s;
     }
-    if (const int ns = split_ffn ? 0 : small_path_splits(M, d, F)) {
+    if (!split_ffn && g_ffn_height == 1 && ffn_height_plan(M, d, F)) {
+      // 1.4 - 3 16-row tiles per CU: one 32- / 48-row tile per CU, out-proj + LN1 + FFN + LN2 in one launch, in place
+      TIMED(FFD_K_FFN, launch_oproj_ffn_ln(ctx->attn, cur, w, cur, M, d, F, s));
+    } else if (const int ns = split_ffn ? 0 : small_path_splits(M, d, F)) {
       // small M: out-proj + LN1 recomputed per F split, FFN partials + a deterministic reduce / LN2 launch
       const size_t need = small_path_partial_floats(M, d, ns);
       if (need > ctx->ffn_part_floats) {
@@ -1429,6 +1437,8 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
   switch (kernel_class) {
     case FFD_K_FFN:  // 4 d F FLOP per row; x in, y out, both weight matrices once
       if (tr && g_ffn_split) name = "k_ffn_ln_split", fl = 4.0 * M * d * F, by = 4.0 * (2.0 * M * d) + 6.0 * (2.0 * d * F);
+      else if (tr && g_ffn_height == 1 && ffn_height_plan((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
+        name = "k_ffn_ln<oproj>", fl = 4.0 * M * d * F + 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
       else if (tr && small_path_splits((int)M, m.d_model, m.dim_feedforward))  // + the out-projection it absorbs
         name = "k_oproj_ffn_split + k_ffn_reduce_ln", fl = 4.0 * M * d * F + 2.0 * M * d * d,
         by = 4.0 * (3.0 * M * d + 2.0 * d * F + d * d);
@@ -1453,6 +1463,7 @@ const char* ffd_kernel_work(const ffd_ctx* ctx, int kernel_class, int B, int cac
       }
       break;
     case FFD_K_OUTPROJ:  // attention output + residual in, LN1 output out
+      if (tr && !g_ffn_split && g_ffn_height == 1 && ffn_height_plan((int)M, m.d_model, m.dim_feedforward)) break;  // inside k_ffn_ln<oproj>
       if (int a_ = 0, b_ = 0, u_ = 0; !g_ffn_split && tr && !small_path_splits((int)M, m.d_model, m.dim_feedforward) &&
                                        rows_slice_plan((int)M, m.d_model, m.dim_feedforward, &a_, &b_, &u_)) {
         if (u_) name = "k_linear_res_ln", fl = 2.0 * M * d * d, by = 4.0 * (3.0 * M * d + d * d);

@@ -38,13 +38,20 @@ namespace ffd {
 //   W2[c0 + 4g + i][16 fc + 4q + r] * H^T[16 fc + 4q + r][16 mb + 4 mq + j],  q = lane>>4, mq = (lane>>2)&3,
 // so each lane-quarter q accumulates the partial sum over its hidden units and the four
 // partials are added with two cross-lane xor-adds once per tile.
-template <int D, int MB, bool REM>
+// OP (round 4, the one-tile forms MB <= 3 only): X is the ATTENTION OUTPUT and the workgroup first forms
+// x1 = LN1(Rres + X Wo^T + bo) of its rows (cached_transformer.py:316-322; the prologue of k_oproj_ffn_split at 16 MB rows:
+// 90 MB MFMAs over the four waves) instead of reading x1 from a k_linear_res_ln launch.  Y may be Rres (a workgroup reads
+// and writes its own rows only).
+struct FfnOprojArgs {
+  const float *Rres, *Wop, *bo, *g1, *e1;
+};
+template <int D, int MB, bool REM, bool OP = false>
 __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* __restrict__ X, const float* __restrict__ W1p,
                                                   const float* __restrict__ b1, const float* __restrict__ W2p,
                                                   const float* __restrict__ W2r, const float* __restrict__ b2,
                                                   const float* __restrict__ gam, const float* __restrict__ bet,
                                                   float* __restrict__ Y, int M, int F,
-                                                  unsigned long long* __restrict__ stamp) {
+                                                  unsigned long long* __restrict__ stamp, FfnOprojArgs op) {
   // stamp (diagnostic launches of ffd_probe_ffn_clock only, nullptr otherwise): shader-clock and 100 MHz real-time
   // deltas around the main loops, written to memory nothing else reads (MI355X_MICROARCH.md, DVFS item 6)
   constexpr int S = lds_stride(D);
@@ -92,6 +99,96 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
   int buf = 0;
   if (DMA) {
     issue_dma(tile, 0);
+  } else if constexpr (OP) {
+    static_assert(!OP || (!DMA && D % 4 == 0), "fused out-projection: the one-tile forms");
+    constexpr int D4 = D / 4;
+    float* pre = red;  // [R][S2]: residual rows -> pre-LN1 rows (the partial-sum buffers are free until the tile end)
+    const int rows_valid = min(R, M - tile * R);
+    const int n = lane & 15, q = lane >> 4;
+    // this wave's out-projection column tiles ct = wave, wave + 4 (requested under the staging)
+    const float4* Woq = reinterpret_cast<const float4*>(op.Wop);
+    float4 wo[2][G];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ct = wave + 4 * i;
+#pragma unroll
+      for (int g = 0; g < G; ++g) wo[i][g] = ct < CTP ? Woq[((size_t)ct * G + g) * 64 + lane] : float4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int f = threadIdx.x; f < R * D4; f += 256) {
+      const int rr = f / D4, c4 = f - rr * D4;
+      const size_t off = (size_t)(tile * R + min(rr, rows_valid - 1)) * D + 4 * c4;
+      const float4 a = *reinterpret_cast<const float4*>(X + off);
+      const float4 x = *reinterpret_cast<const float4*>(op.Rres + off);
+      float2* d2 = reinterpret_cast<float2*>(&xsb[rr * SX + 4 * c4]);
+      d2[0] = float2{a.x, a.y}, d2[1] = float2{a.z, a.w};
+      *reinterpret_cast<float4*>(&pre[rr * S2 + 4 * c4]) = x;
+    }
+    __syncthreads();
+    // out-projection + bias + residual: lane holds columns c .. c+3 of row 16 mb + n
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      float af[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) af[s] = xsb[(16 * mb + n) * SX + 4 * s + q];
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float4 w4 = wo[i][s >> 2];
+          const float a = (s & 3) == 0 ? w4.x : (s & 3) == 1 ? w4.y : (s & 3) == 2 ? w4.z : w4.w;
+          acc[i] = mfma16(a, af[s], acc[i]);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = 16 * (wave + 4 * i) + 4 * q;
+        if (wave + 4 * i < CTP && c < D) {
+          const float4 b4 = *reinterpret_cast<const float4*>(op.bo + c);
+          float4* p4 = reinterpret_cast<float4*>(&pre[(16 * mb + n) * S2 + c]);
+          const float4 x4 = *p4;
+          *p4 = float4{acc[i][0] + b4.x + x4.x, acc[i][1] + b4.y + x4.y, acc[i][2] + b4.z + x4.z, acc[i][3] + b4.w + x4.w};
+        }
+      }
+    }
+    __syncthreads();
+    // LayerNorm1: 16 threads per row, 16 rows per pass; x1 -> the X image (the FFN's input and LN2's residual)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const int row = 16 * mb + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+      float4 v[2];
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = sub + 16 * i;
+        v[i] = c4 < D4 ? *reinterpret_cast<const float4*>(&pre[row * S2 + 4 * c4]) : float4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+      const float mean = sum * (1.0f / D);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        if (sub + 16 * i < D4) {
+          const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+          ss = fmaf(a, a, ss), ss = fmaf(b, b, ss), ss = fmaf(c, c, ss), ss = fmaf(d, d, ss);
+        }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+      const float rstd = 1.0f / sqrtf(ss * (1.0f / D) + 1e-5f);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c4 = sub + 16 * i;
+        if (c4 < D4) {
+          const float4 g4 = *reinterpret_cast<const float4*>(op.g1 + 4 * c4), e4 = *reinterpret_cast<const float4*>(op.e1 + 4 * c4);
+          const float4 o = {(v[i].x - mean) * rstd * g4.x + e4.x, (v[i].y - mean) * rstd * g4.y + e4.y,
+                            (v[i].z - mean) * rstd * g4.z + e4.z, (v[i].w - mean) * rstd * g4.w + e4.w};
+          float2* d2 = reinterpret_cast<float2*>(&xsb[row * SX + 4 * c4]);
+          d2[0] = float2{o.x, o.y}, d2[1] = float2{o.z, o.w};
+        }
+      }
+    }
+    // (the barrier at the top of the tile loop orders these x1 writes before the fragment reads)
   } else {
     // ---- stage the X tile (coalesced float4) ----
     const float4* X4 = reinterpret_cast<const float4*>(X + (size_t)tile * R * D);
@@ -312,9 +409,12 @@ __global__ __launch_bounds__(256, (MB <= 4 ? 2 : 1)) void k_ffn_ln(const float* 
     }
 
     // ---- + b2, LayerNorm2, coalesced store ----
-    constexpr int TPR = 256 / R;  // threads per row (2..16), power of two
-    const int row = tid_e / TPR, sub = tid_e % TPR;
-    const int m = m0 + row;
+    // threads per row, a power of two (tile heights of 48 / 80 / 96 rows leave the threads past the last row idle)
+    constexpr int TPR = R <= 16 ? 16 : R <= 32 ? 8 : R <= 64 ? 4 : 2;
+    static_assert(R * TPR <= 256, "a thread group per row");
+    const bool row_on = tid_e / TPR < R;
+    const int row = row_on ? tid_e / TPR : R - 1, sub = tid_e % TPR;
+    const int m = row_on ? m0 + row : M;  // (idle threads: in-range LDS reads, no store)
     if constexpr (DMA && D % 4 == 0) {
       // whole float4 columns c4 = sub, sub + TPR, ... (images with 16-byte aligned rows)
       constexpr int NV = cdiv(D / 4, TPR);
@@ -430,6 +530,21 @@ int num_cus() {
   }
   return n;
 }
+thread_local int g_ffn_height = 1;  // ffd_tune "ffn_height": tile heights of 32 / 48 rows where the 16-row tiles are 1.4 - 3 per CU: 1 with the out-projection + LN1 inside, 2 behind a k_linear_res_ln launch; 0 off
+// Between the small-batch pair and the sliced row-owning kernel (ECG: B = 28 ... 65, the reference's default
+// sample_batch_size of 50 among them): 16 MB rows per workgroup with MB = the 16-row tiles per CU, so that every CU takes
+// one tile and its four waves split F -- 320 ... 512 16-row tiles: 32-row tiles, 513 ... 768: 48-row tiles, with the
+// out-projection + LN1 as the tile's prologue (tools/sweep_tile_heights.py, ms per step before -> behind a
+// k_linear_res_ln launch -> in one launch: B = 32 0.688 -> 0.661 -> 0.627, B = 40 0.760 -> 0.671 -> 0.631, B = 50
+// 0.958 -> 0.903 -> 0.874, B = 64 1.086 -> 0.920 -> 0.885; from 769 tiles on the 64-row forms were as fast already: a tile
+// costs ~ 13 us + 16.2 us per 16 rows, 15.6 of them matrix time).  0 = another form.
+int ffn_height_plan(int M, int D, int F) {
+  if (!g_ffn_height || g_ffn_mb_override != 0 || g_ffn_split || D % 4 != 0 || D > 72 || F % 64 != 0) return 0;
+  const int t16 = cdiv(M, 16), cus = num_cus();
+  if (4 * t16 >= 5 * cus && t16 <= 2 * cus) return 2;
+  if (t16 > 2 * cus && t16 <= 3 * cus) return 3;
+  return 0;
+}
 thread_local int g_ffn_rem = 1;          // 1: remainder rows of GEMM2 on the 4x4x1 MFMA (ffd_tune "ffn_rem")
 thread_local int g_ffn_mb_override = 0;  // 0 = heuristic; 1 / 2 / 4 forces the tile height (ffd_tune "ffn_mb"; the 128-row MB = 8 instances -- never
                             // selected, 400-656 B of scratch at d_model >= 48 -- were retired in round 4)
@@ -440,9 +555,10 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   // Tile height 16*MB rows.  MB = 4 keeps two workgroups (two waves per SIMD) resident per CU
   // and is the default once the grid fills the chip; smaller tiles for small batches.
   int mb = g_ffn_mb_override;
-  if (mb != 1 && mb != 2 && mb != 4) {
+  if (mb < 1 || mb > 4) {
     const int target = 2 * 256;
     mb = cdiv(M, 64) >= target ? 4 : cdiv(M, 32) >= target ? 2 : 1;
+    if (const int hp = ffn_height_plan(M, D, F)) mb = hp;
   }
   dim3 block(256);
   // MB >= 4 is persistent: as many workgroups as the chip holds (two per CU at MB = 4, one at MB = 8)
@@ -453,25 +569,63 @@ static hipError_t launch_ffn_d(const float* X, const LayerWeights& w, float* Y, 
   };
 #define FFD_LAUNCH_FFN(MBV)                                                                                       \
   do {                                                                                                            \
-    if (g_ffn_rem && MBV == 4 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
+    if (g_ffn_rem && MBV >= 3 && D >= 16 && w2rem_groups(D) > 0)                                                                       \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, true>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,             \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp, FfnOprojArgs{});                      \
     else                                                                                                          \
       hipLaunchKernelGGL((k_ffn_ln<D, MBV, false>), grid_of(MBV), block, 0, s, X, w.w1p, w.b1, w.w2p,            \
-                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp);                                      \
+                         w.w2r, w.b2, w.n2w, w.n2b, Y, M, F, stamp, FfnOprojArgs{});                      \
   } while (0)
   switch (mb) {
     case 4: FFD_LAUNCH_FFN(4); break;
     case 2: FFD_LAUNCH_FFN(2); break;
+    case 3: FFD_LAUNCH_FFN(3); break;
     default: FFD_LAUNCH_FFN(1); break;
   }
 #undef FFD_LAUNCH_FFN
   return hipGetLastError();
 }
 
+// y = LN2(x1 + FFN(x1)), x1 = LN1(Rres + attn Wo^T + bo) in ONE launch where ffn_height_plan applies (one 32- / 48-row
+// tile per CU; cached_transformer.py:316-327).  Y may be Rres.
+template <int D>
+static hipError_t launch_oproj_ffn_d(const float* attn, const float* Rres, const LayerWeights& w, float* Y, int M, int F,
+                                     int mb, hipStream_t s) {
+  const FfnOprojArgs op{Rres, w.out_wp, w.out_b, w.n1w, w.n1b};
+  const dim3 block(256), grid(cdiv(M, 16 * mb));
+  if (mb == 3) {
+    if (g_ffn_rem && D >= 16 && w2rem_groups(D) > 0)
+      hipLaunchKernelGGL((k_ffn_ln<D, 3, true, true>), grid, block, 0, s, attn, w.w1p, w.b1, w.w2p, w.w2r, w.b2, w.n2w, w.n2b,
+                         Y, M, F, nullptr, op);
+    else
+      hipLaunchKernelGGL((k_ffn_ln<D, 3, false, true>), grid, block, 0, s, attn, w.w1p, w.b1, w.w2p, w.w2r, w.b2, w.n2w,
+                         w.n2b, Y, M, F, nullptr, op);
+  } else if (mb == 2) {
+    hipLaunchKernelGGL((k_ffn_ln<D, 2, false, true>), grid, block, 0, s, attn, w.w1p, w.b1, w.w2p, w.w2r, w.b2, w.n2w, w.n2b,
+                       Y, M, F, nullptr, op);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_oproj_ffn_ln(const float* attn, const float* Rres, const LayerWeights& w, float* Y, int M, int D, int F,
+                               hipStream_t s) {
+  const int mb = ffn_height_plan(M, D, F);
+  if (M <= 0) return hipSuccess;
+  if (!mb || w.out_wp == nullptr) return hipErrorInvalidValue;
+  switch (D) {
+#define X(d) \
+    case d: return launch_oproj_ffn_d<d>(attn, Rres, w, Y, M, F, mb, s);
+    FFD_D_LIST(X)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+}
+
 int ffn_tile_rows(int M) {  // rows per workgroup launch_ffn_ln picks (one stamp pair per workgroup)
   int mb = g_ffn_mb_override;
-  if (mb != 1 && mb != 2 && mb != 4) mb = cdiv(M, 64) >= 512 ? 4 : cdiv(M, 32) >= 512 ? 2 : 1;
+  if (mb < 1 || mb > 4) mb = cdiv(M, 64) >= 512 ? 4 : cdiv(M, 32) >= 512 ? 2 : 1;  // (+ ffn_height_plan: the callers that stamp pass large M)
   return 16 * mb;
 }
 

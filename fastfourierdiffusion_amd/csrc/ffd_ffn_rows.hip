@@ -768,6 +768,7 @@ thread_local int g_rows_slices = 0;  // sliced form of the fused kernel: 0 heuri
 thread_local int g_rows_slices_fuse = 0;  // 0 heuristic, 1 fused only, 2 unfused only (ffd_tune "rows_slices_fuse")
 bool rows_slice_plan(int M, int D, int F, int* nw_out, int* nslice_out, int* unfused_out) {
   if (g_rows_slices < 0 || !g_ffn_rows || !g_ffn_rows_fuse || g_ffn_rows_cps == 1 || !ffn_rows_supported(D, F)) return false;
+  if (g_rows_slices == 0 && ffn_height_plan(M, D, F)) return false;  // (one 32- / 48-row k_ffn_ln tile per CU there)
   const int nslots = F / 64;
   double best = 1e30;
   int bnw = 0, bs = 0, bunf = 0;

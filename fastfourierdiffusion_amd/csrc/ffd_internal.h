@@ -129,6 +129,12 @@ hipError_t launch_linear_res_ln(const float* X, const float* Wp, const float* bi
 hipError_t launch_ffn_ln(const float* X, const LayerWeights& w, float* Y, int M, int D, int F, hipStream_t s,
                          unsigned long long* stamp = nullptr);
 int ffn_tile_rows(int M);
+// 16-row tiles per CU between 1.4 and 3: k_ffn_ln at 32 / 48 rows per workgroup (one tile per CU); 0 = another form
+int ffn_height_plan(int M, int D, int F);
+// ... as ONE launch, out-projection + LN1 inside (g_ffn_height == 1); Y may be Rres
+hipError_t launch_oproj_ffn_ln(const float* attn, const float* Rres, const LayerWeights& w, float* Y, int M, int D, int F,
+                               hipStream_t s);
+extern thread_local int g_ffn_height;
 // Row-owning FFN with a CU-shared LDS weight ring (ffd_ffn_rows.hip): the large-M form
 bool ffn_rows_supported(int D, int F);
 bool ffn_rows_selected(int M, int D, int F);

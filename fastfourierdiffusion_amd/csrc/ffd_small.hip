@@ -432,6 +432,7 @@ thread_local int g_small_path = 1;  // ffd_tune "small_path": 0 disables the spl
 // 16-row tiles no longer fit the chip in one round and 64-row tiles leave half of it idle).
 int small_path_splits(int M, int D, int F) {
   if (!g_small_path || D % 4 != 0 || D > 128 || F % 64 != 0) return 0;
+  if (g_small_wgs == 0 && ffn_height_plan(M, D, F)) return 0;  // (one 32- / 48-row tile per CU is the faster form there)
   const int tiles = cdiv(M, 16);
   const int caps[2] = {g_small_wgs > 0 ? g_small_wgs : 5 * num_cus() / 2, g_small_wgs > 0 ? g_small_wgs : 6 * num_cus()};
   for (int cap : caps)
@@ -453,6 +454,7 @@ thread_local int g_mid_path = 1;  // ffd_tune "mid_path": 0 off, 1 heuristic, 2 
 // two slices were never better than four, eight only equal.
 int mid_path_splits(int M, int D, int F) {
   if (!g_mid_path || D % 4 != 0 || D > 128) return 0;
+  if (g_mid_path == 1 && ffn_height_plan(M, D, F)) return 0;
   if (g_mid_path > 1) return (F / 64) % g_mid_path == 0 ? g_mid_path : 0;
   if ((F / 64) % 4 != 0) return 0;
   const int tiles = cdiv(M, 64), cus = num_cus();

@@ -1416,6 +1416,52 @@ def test_rows_sliced_form_agrees_with_the_other_forms(ffd, name, batches):
         assert rel_err(auto.cpu(), ref.cpu()) < 2e-6, B
 
 
+@pytest.mark.parametrize("name,batches", [("ecg", (32, 40, 50, 64)), ("syn", (12, 20))])
+def test_tile_height_form_agrees_with_the_other_forms(ffd, name, batches):
+    """Where the 16-row tiles are 1.4 - 3 per CU (ECG: B = 30 ... 65, the reference's default sample_batch_size of 50
+    among them) the feed-forward block runs as k_linear_res_ln + k_ffn_ln at 32 / 48 rows per workgroup, one tile per
+    CU: equal to the forms it replaces (the small-batch pair, the sliced row-owning kernel, 16- and 64-row tiles) to
+    rounding, deterministic, independent of the batch around a sample; forced heights of 1 ... 4 agree as well."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == name)
+    m, _ = make_model(ffd, c)
+    lib = N.lib()
+    for B in batches:
+        x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 777 + B))).cuda()
+        assert lib.ffd_tune(b"reset", 0) == 0
+        a = m(batch_of(x, 0.6))
+        assert torch.equal(a, m(batch_of(x, 0.6))), B
+        assert lib.ffd_tune(b"ffn_height", 0) == 0
+        ref = m(batch_of(x, 0.6))
+        assert rel_err(a.cpu(), ref.cpu()) < 2e-6, B
+        assert lib.ffd_tune(b"ffn_height", 2) == 0  # the same tiles behind a k_linear_res_ln launch
+        u = m(batch_of(x, 0.6))
+        assert torch.equal(u, m(batch_of(x, 0.6))) and rel_err(u.cpu(), ref.cpu()) < 2e-6, B
+        assert lib.ffd_tune(b"reset", 0) == 0
+        part = m(batch_of(x[: B // 2 + 1].contiguous(), 0.6))  # (may be another form: to rounding)
+        assert rel_err(part.cpu(), a[: B // 2 + 1].cpu()) < 2e-6, B
+        for mb in (1, 2, 3, 4):
+            assert lib.ffd_tune(b"small_path", 0) == 0 and lib.ffd_tune(b"rows_slices", -1) == 0
+            assert lib.ffd_tune(b"mid_path", 0) == 0 and lib.ffd_tune(b"ffn_rows", 0) == 0 and lib.ffd_tune(b"ffn_mb", mb) == 0
+            f = m(batch_of(x, 0.6))
+            assert rel_err(f.cpu(), ref.cpu()) < 2e-6, (B, mb)
+            part = m(batch_of(x[: B // 2 + 1].contiguous(), 0.6))  # another tile assignment
+            assert rel_err(part.cpu(), f[: B // 2 + 1].cpu()) < 2e-6, (B, mb)
+        assert lib.ffd_tune(b"reset", 0) == 0
+    # the plan itself: B = 50 at the ECG shape is one 48-row tile per CU
+    if name == "ecg":
+        assert lib.ffd_tune(b"reset", 0) == 0
+        fl, by = C_.c_double(), C_.c_double()
+        ctx = m._ctx()
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 50, 0, C_.byref(fl), C_.byref(by)) == b"k_ffn_ln<oproj>"
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_OUTPROJ, 50, 0, C_.byref(fl), C_.byref(by)) is None
+        assert lib.ffd_tune(b"ffn_height", 2) == 0
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_FFN, 50, 0, C_.byref(fl), C_.byref(by)) == b"k_ffn_ln"
+        assert ctx.lib.ffd_kernel_work(ctx.handle, N.K_OUTPROJ, 50, 0, C_.byref(fl), C_.byref(by)) == b"k_linear_res_ln"
+        assert lib.ffd_tune(b"reset", 0) == 0
+
+
 def test_rows_sliced_form_in_rounds(ffd):
     """Round 4: where tiles x slices exceeds the CUs (ECG B = 384: 187 tiles x 4 slices) the sliced form's workgroups walk
     several tiles of their slice: bit-identical with the one-round result of the same slicing wherever both exist (a
