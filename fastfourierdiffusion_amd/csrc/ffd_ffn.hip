@@ -531,16 +531,18 @@ int num_cus() {
   return n;
 }
 thread_local int g_ffn_height = 1;  // ffd_tune "ffn_height": tile heights of 32 / 48 rows where the 16-row tiles are 1.4 - 3 per CU: 1 with the out-projection + LN1 inside, 2 behind a k_linear_res_ln launch; 0 off
-// Between the small-batch pair and the sliced row-owning kernel (ECG: B = 28 ... 65, the reference's default
+// Between the small-batch pair and the sliced row-owning kernel (ECG: B = 12 ... 21 and 28 ... 65, the reference's default
 // sample_batch_size of 50 among them): 16 MB rows per workgroup with MB = the 16-row tiles per CU, so that every CU takes
-// one tile and its four waves split F -- 320 ... 512 16-row tiles: 32-row tiles, 513 ... 768: 48-row tiles, with the
-// out-projection + LN1 as the tile's prologue (tools/sweep_tile_heights.py, ms per step before -> behind a
+// one tile and its four waves split F -- 141 ... 256 16-row tiles: one each (B = 16: 0.479 -> 0.430 ms per step, B = 20:
+// 0.485 -> 0.432; below 0.55 tiles per CU the F-split pair's finer units win), 320 ... 512: 32-row tiles, 513 ... 768:
+// 48-row tiles, with the out-projection + LN1 as the tile's prologue (tools/sweep_tile_heights.py, ms per step before -> behind a
 // k_linear_res_ln launch -> in one launch: B = 32 0.688 -> 0.661 -> 0.627, B = 40 0.760 -> 0.671 -> 0.631, B = 50
 // 0.958 -> 0.903 -> 0.874, B = 64 1.086 -> 0.920 -> 0.885; from 769 tiles on the 64-row forms were as fast already: a tile
 // costs ~ 13 us + 16.2 us per 16 rows, 15.6 of them matrix time).  0 = another form.
 int ffn_height_plan(int M, int D, int F) {
   if (!g_ffn_height || g_ffn_mb_override != 0 || g_ffn_split || D % 4 != 0 || D > 72 || F % 64 != 0) return 0;
   const int t16 = cdiv(M, 16), cus = num_cus();
+  if (20 * t16 >= 11 * cus && t16 <= cus) return 1;
   if (4 * t16 >= 5 * cus && t16 <= 2 * cus) return 2;
   if (t16 > 2 * cus && t16 <= 3 * cus) return 3;
   return 0;
@@ -602,6 +604,9 @@ static hipError_t launch_oproj_ffn_d(const float* attn, const float* Rres, const
                          w.n2b, Y, M, F, nullptr, op);
   } else if (mb == 2) {
     hipLaunchKernelGGL((k_ffn_ln<D, 2, false, true>), grid, block, 0, s, attn, w.w1p, w.b1, w.w2p, w.w2r, w.b2, w.n2w, w.n2b,
+                       Y, M, F, nullptr, op);
+  } else if (mb == 1) {
+    hipLaunchKernelGGL((k_ffn_ln<D, 1, false, true>), grid, block, 0, s, attn, w.w1p, w.b1, w.w2p, w.w2r, w.b2, w.n2w, w.n2b,
                        Y, M, F, nullptr, op);
   } else {
     return hipErrorInvalidValue;

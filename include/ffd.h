@@ -299,10 +299,11 @@ int ffd_sample_batch(ffd_ctx* ctx, float* x, int B, const float* timesteps, int 
  * selects kernels for the launches THAT thread makes and is invisible to every other thread, so two samplers on two
  * threads cannot disturb each other; a thread starts from the defaults.  ffd_tune_get reads the calling thread's value.
  *   "ffn_mb" = 0 (heuristic) | 1 | 2 | 3 | 4   rows/16 per workgroup of k_ffn_ln;
- *   "ffn_height" = 1 | 2 | 0                   where the 16-row tiles are 1.4 - 3 per CU (ECG: B = 30 ... 65, the reference's
- *                                              default sample_batch_size of 50 among them): k_ffn_ln at 32 / 48 rows per
- *                                              workgroup, one tile per CU, with the out-projection + LN1 inside (1) or behind
- *                                              a k_linear_res_ln launch (2) | 0: the small-batch pair / sliced forms;
+ *   "ffn_height" = 1 | 2 | 0                   where the 16-row tiles are 0.55 - 1 or 1.25 - 3 per CU (ECG: B = 12 ... 21 and
+ *                                              28 ... 65, the reference's default sample_batch_size of 50 among them):
+ *                                              k_ffn_ln at 16 / 32 / 48 rows per workgroup, one tile per CU, with the
+ *                                              out-projection + LN1 inside (1) or behind a k_linear_res_ln launch (2) |
+ *                                              0: the small-batch pair / sliced forms;
  *   "reset" (value ignored)                    every knob below back to its default;
  *   "ffn_rows" = 1 | 0 | 2                     FFN at large M (d_model 72 / 64 / 60 / 48): row-owning waves + CU-shared LDS weight ring
  *                                              (k_ffn_rows, ffd_ffn_rows.hip) or the F-split workgroup (k_ffn_ln); 2 = at
