@@ -26,6 +26,7 @@ struct DevBuf {
 struct LstmLayer {
   const float *wih, *whh, *bih, *bhh;
   float *wih_p, *bsum;
+  float *ih_wpk = nullptr, *hh_wpk = nullptr, *b_wpk = nullptr;  // k_lstm_wave's fragment-ordered packs (d_model % 4 == 0, >= 16)
 };
 
 struct LayerPacked {
@@ -657,6 +658,11 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
         int rc;
         if ((rc = dev_alloc(ctx, &l.wih_p, dpack_floats(4 * d, d)))) return rc;
         if ((rc = dev_alloc(ctx, &l.bsum, 4 * d))) return rc;
+        if (d % 4 == 0 && d >= 16) {
+          if ((rc = dev_alloc(ctx, &l.ih_wpk, lstm_wave_wpack_floats(d)))) return rc;
+          if ((rc = dev_alloc(ctx, &l.hh_wpk, lstm_wave_wpack_floats(d)))) return rc;
+          if ((rc = dev_alloc(ctx, &l.b_wpk, lstm_wave_bpack_floats(d)))) return rc;
+        }
       }
       l.wih = W(pre + "weight_ih_l0");
       l.whh = W(pre + "weight_hh_l0");
@@ -665,6 +671,7 @@ int ffd_finalize_weights(ffd_ctx* ctx) {
       HIPCHECK(launch_pack_dweight(l.wih, l.wih_p, 4 * d, d, s));
       hipLaunchKernelGGL(k_add_vec, dim3(cdiv(4 * d, 256)), dim3(256), 0, s, l.bih, l.bhh, l.bsum, 4 * d);
       HIPCHECK(hipGetLastError());
+      if (l.ih_wpk) HIPCHECK(launch_pack_lstm_wave(l.wih, l.whh, l.bsum, l.ih_wpk, l.hh_wpk, l.b_wpk, d, s));
     }
   }
   HIPCHECK(hipStreamSynchronize(s));
@@ -748,7 +755,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
         ctx->lstm_prog = reinterpret_cast<int*>(pbuf);
       }
       const float *wih[64], *whh[64], *bs[64];
-      for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].wih, whh[i] = ctx->lstm[i].whh, bs[i] = ctx->lstm[i].bsum;
+      for (int i = 0; i < m.num_layers; ++i) wih[i] = ctx->lstm[i].ih_wpk, whh[i] = ctx->lstm[i].hh_wpk, bs[i] = ctx->lstm[i].b_wpk;
       const size_t need_st = lstm_wave_state_floats(Bw, d, m.num_layers);
       if (need_st > ctx->lstm_state_floats) {
         if (int rc = dev_regrow(ctx, &ctx->lstm_state, need_st, &ctx->lstm_state_floats, need_st)) return rc;

@@ -220,9 +220,14 @@ hipError_t launch_lstm_layer(float* x, const float* gx, const float* whh, int B,
 bool lstm_wave_selected(int B, int D);
 int lstm_wave_max_batch(int L, int D);  // samples one k_lstm_wave launch takes (a 16-sample tile per CU, rows < 2^31 bytes); larger batches go in sub-batches
 extern thread_local int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk, g_lstm_wave_fault, g_lstm_wave_spin_ms;
-hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
+hipError_t launch_lstm_wave(float* x, const float* const* wih_pk, const float* const* whh_pk, const float* const* bias_pk, int NL,
                             int B, int L, int D, int* prog, float* state, int* err, hipStream_t s);
 size_t lstm_wave_state_floats(int B, int D, int NL);
+// launch_lstm_wave takes the weights in k_lstm_wave's fragment order (one pack per role and layer + the summed bias)
+size_t lstm_wave_wpack_floats(int D);
+size_t lstm_wave_bpack_floats(int D);
+hipError_t launch_pack_lstm_wave(const float* wih, const float* whh, const float* bsum, float* ih_out, float* hh_out,
+                                 float* b_out, int D, hipStream_t s);
 
 hipError_t launch_dense(const float* X, const float* W, const float* b, const float* b2, const float* R, float* Y,
                         int M, int N, int K, int relu, hipStream_t s);

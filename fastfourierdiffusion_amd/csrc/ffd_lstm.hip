@@ -289,18 +289,24 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   // registers, prefetched at the end of the previous unit, they cost the kernel its register budget: 1 KB of scratch).
   float wf[NTW][NT];
   f32x4 bias[NTW];
+  // (round 4: from the fragment-ordered packs of k_pack_lstm_wave -- whole float4, every wave instruction one contiguous
+  //  KiB: 25 + 5 loads per lane at d_model 72 where the (out, in) matrices took 90 + 20 scalar ones, each touching 16 rows)
+  constexpr int S4W = (NT + 3) / 4;  // float4 groups of a tile's NT k-steps
   auto load_weights = [&](int layer) {
-    const float* wsrc = recur ? wa.whh[layer] : wa.wih[layer];
-    const float* bsum = wa.bsum[layer];
+    const float4* wp = reinterpret_cast<const float4*>(recur ? wa.whh[layer] : wa.wih[layer]) + (size_t)wave * NTW * S4W * 64 + lane;
+    const float4* bp = reinterpret_cast<const float4*>(wa.bsum[layer]) + (size_t)wave * NTW * 64 + lane;
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
-      const int Tt = min(t0 + tt, NT - 1);
-      const bool on = tt < ntw;
-      const size_t row = (size_t)((j & 3) * D + 4 * Tt + (j >> 2)) * D;
 #pragma unroll
-      for (int s = 0; s < NT; ++s) wf[tt][s] = on ? wsrc[row + 4 * s + q] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias[tt][r] = on ? bsum[r * D + 4 * Tt + q] : 0.f;
+      for (int g = 0; g < S4W; ++g) {
+        const float4 v = wp[(tt * S4W + g) * 64];
+        if (4 * g + 0 < NT) wf[tt][4 * g + 0] = v.x;
+        if (4 * g + 1 < NT) wf[tt][4 * g + 1] = v.y;
+        if (4 * g + 2 < NT) wf[tt][4 * g + 2] = v.z;
+        if (4 * g + 3 < NT) wf[tt][4 * g + 3] = v.w;
+      }
+      const float4 b4 = bp[tt * 64];
+      bias[tt] = f32x4{b4.x, b4.y, b4.z, b4.w};
     }
   };
 
@@ -537,6 +543,54 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   __syncthreads();
   if (tg == 0 && !mute) __hip_atomic_store(my_prog, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }  // units
+}
+
+// Fragment-ordered weights of k_lstm_wave: per role (W_hh, W_ih) [wave 4][tile slot NTW][k group S4W][lane 64][4] =
+// W[row(lane & 15, tile)][4 (4 g + j) + (lane >> 4)] with row = (gate = i & 3) D + 4 tile + (i >> 2) -- the A operand of the
+// cell step, tile = the wave's tt-th unit tile (5 / 5 / 4 / 4 of 18 at d_model 72; slots past a wave's share are zero) -- and
+// the summed bias [wave][slot][lane][gate r] = b[r D + 4 tile + (lane >> 4)].
+template <int D>
+__global__ void k_pack_lstm_wave(const float* __restrict__ wih, const float* __restrict__ whh, const float* __restrict__ bsum,
+                                 float* __restrict__ ih_out, float* __restrict__ hh_out, float* __restrict__ b_out) {
+  constexpr int NT = D / 4, NTW = (NT + 3) / 4, S4W = (NT + 3) / 4;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of each role's pack
+  if (idx >= 4 * NTW * S4W * 64) return;
+  const int lane = idx & 63, g = (idx >> 6) % S4W, tt = ((idx >> 6) / S4W) % NTW, wave = (idx >> 6) / (S4W * NTW);
+  const int t0 = wave * (NT / 4) + min(wave, NT % 4), ntw = NT / 4 + (wave < NT % 4 ? 1 : 0);
+  const int Tt = min(t0 + tt, NT - 1), j = lane & 15, q = lane >> 4;
+  const bool on = tt < ntw;
+  const size_t row = (size_t)((j & 3) * D + 4 * Tt + (j >> 2)) * D;
+  float a[4], b[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int s = 4 * g + c;
+    const bool in = on && s < NT;
+    a[c] = in ? wih[row + 4 * s + q] : 0.f;
+    b[c] = in ? whh[row + 4 * s + q] : 0.f;
+  }
+  reinterpret_cast<float4*>(ih_out)[idx] = float4{a[0], a[1], a[2], a[3]};
+  reinterpret_cast<float4*>(hh_out)[idx] = float4{b[0], b[1], b[2], b[3]};
+  if (g == 0) {
+    float4 bb{0.f, 0.f, 0.f, 0.f};
+    if (on) bb = float4{bsum[0 * D + 4 * Tt + q], bsum[1 * D + 4 * Tt + q], bsum[2 * D + 4 * Tt + q], bsum[3 * D + 4 * Tt + q]};
+    reinterpret_cast<float4*>(b_out)[(wave * NTW + tt) * 64 + lane] = bb;
+  }
+}
+
+// floats of one role's weight pack / of the bias pack
+size_t lstm_wave_wpack_floats(int D) { return (size_t)4 * ((D / 4 + 3) / 4) * ((D / 4 + 3) / 4) * 64 * 4; }
+size_t lstm_wave_bpack_floats(int D) { return (size_t)4 * ((D / 4 + 3) / 4) * 64 * 4; }
+hipError_t launch_pack_lstm_wave(const float* wih, const float* whh, const float* bsum, float* ih_out, float* hh_out,
+                                 float* b_out, int D, hipStream_t s) {
+  const int n4 = (int)(lstm_wave_wpack_floats(D) / 4);
+  switch (D) {
+#define X(d) \
+  case d: hipLaunchKernelGGL(k_pack_lstm_wave<d>, dim3(cdiv(n4, 256)), dim3(256), 0, s, wih, whh, bsum, ih_out, hh_out, b_out); break;
+    X(16) X(24) X(32) X(48) X(60) X(64) X(72)
+#undef X
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
 }
 
 constexpr size_t lstm_wave_lds(int D) { return (size_t)(2 * (D / 4) * 64 * 4 + 5 * 16 * (D + 2)) * 4; }
