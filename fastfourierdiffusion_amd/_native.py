@@ -85,6 +85,7 @@ SIGNATURES = {
     "ffd_positional_encoding": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "ffd_time_encoding": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "ffd_fresca": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double, C.c_int, _P]),
+    "ffd_lstm_trace": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     "ffd_fresca2d": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_double, C.c_int, _P]),
     "ffd_fresca_enable": (C.c_int, [_P, C.POINTER(FrescaCfg)]),
     "ffd_fresca_disable": (C.c_int, [_P]),

@@ -88,6 +88,8 @@ struct ffd_ctx {
   float* lstm_state = nullptr;  // (tile, layer) state blocks of the time-chunked wavefront
   size_t lstm_state_floats = 0;
   float* ffn_part = nullptr;  // partial Y tiles of the small-M split FFN
+  unsigned long long* lstm_trace = nullptr;  // ffd_lstm_trace: per-unit records of the next k_lstm_wave launch
+  int lstm_trace_units = 0;
   size_t ffn_part_floats = 0;
   // FreSca (sampler-level)
   bool fresca_on = false;
@@ -763,7 +765,7 @@ static int forward_impl(ffd_ctx* ctx, const float* x, const float* temb, int tem
       for (int b0 = 0; b0 < B; b0 += Bw) {  // (samples are independent: sub-batches of a tile per CU, one after the other)
         const int nb = B - b0 < Bw ? B - b0 : Bw;
         TIMED(FFD_K_LSTM_REC, launch_lstm_wave(ctx->h0 + (size_t)b0 * L * d, wih, whh, bs, m.num_layers, nb, L, d,
-                                               ctx->lstm_prog, ctx->lstm_state, ctx->async_err, s));
+                                               ctx->lstm_prog, ctx->lstm_state, ctx->async_err, s, b0 == 0 ? ctx->lstm_trace : nullptr));
       }
     } else
     for (int i = 0; i < m.num_layers; ++i) {
@@ -1388,6 +1390,27 @@ double ffd_ffn_flops_per_launch(const ffd_ctx* ctx, int B) {
   if (!ctx) return 0.0;
   const ffd_model_desc& m = ctx->desc;
   return 4.0 * (double)B * m.max_len * m.d_model * m.dim_feedforward;
+}
+
+int ffd_lstm_trace(ffd_ctx* ctx, unsigned long long* host_out, int capacity_units, int* n_units_out) {
+  if (!ctx || capacity_units < 1) return FFD_ERR_INVALID;
+  HIPCHECK(hipSetDevice(ctx->device));
+  if (host_out == nullptr) {  // begin: the next k_lstm_wave launches write their units' records
+    if (ctx->lstm_trace) (void)hipFree(ctx->lstm_trace);
+    ctx->lstm_trace = nullptr;
+    HIPCHECK(hipMalloc(&ctx->lstm_trace, sizeof(unsigned long long) * 4 * (size_t)capacity_units));
+    HIPCHECK(hipMemset(ctx->lstm_trace, 0, sizeof(unsigned long long) * 4 * (size_t)capacity_units));
+    ctx->lstm_trace_units = capacity_units;
+    return FFD_OK;
+  }
+  if (!ctx->lstm_trace) return ctx->fail(FFD_ERR_STATE, "ffd_lstm_trace: no trace begun");
+  HIPCHECK(hipDeviceSynchronize());
+  const int n = capacity_units < ctx->lstm_trace_units ? capacity_units : ctx->lstm_trace_units;
+  HIPCHECK(hipMemcpy(host_out, ctx->lstm_trace, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(ctx->lstm_trace);
+  ctx->lstm_trace = nullptr;
+  if (n_units_out) *n_units_out = n;
+  return FFD_OK;
 }
 
 int ffd_kernel_timing_begin(ffd_ctx* ctx, uint32_t class_mask, int max_launches) {

@@ -221,7 +221,8 @@ bool lstm_wave_selected(int B, int D);
 int lstm_wave_max_batch(int L, int D);  // samples one k_lstm_wave launch takes (a 16-sample tile per CU, rows < 2^31 bytes); larger batches go in sub-batches
 extern thread_local int g_lstm_wave, g_lstm_wave_persist, g_lstm_wave_per, g_lstm_wave_chunk, g_lstm_wave_fault, g_lstm_wave_spin_ms;
 hipError_t launch_lstm_wave(float* x, const float* const* wih_pk, const float* const* whh_pk, const float* const* bias_pk, int NL,
-                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s);
+                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s,
+                            unsigned long long* trace = nullptr);  // trace: 4 u64 per unit (ffd_lstm_trace), diagnostics
 size_t lstm_wave_state_floats(int B, int D, int NL);
 // launch_lstm_wave takes the weights in k_lstm_wave's fragment order (one pack per role and layer + the summed bias)
 size_t lstm_wave_wpack_floats(int D);

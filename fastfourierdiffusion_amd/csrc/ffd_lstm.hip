@@ -245,7 +245,8 @@ template <int D>
 __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, LstmWaveArgs wa, int n_layers, int n_tiles,
                                                       int T, int B, int L, int* __restrict__ prog,
                                                       float* __restrict__ state, int* __restrict__ err,
-                                                      int* __restrict__ abort_word, unsigned spin_ticks, int fault) {
+                                                      int* __restrict__ abort_word, unsigned spin_ticks, int fault,
+                                                      unsigned long long* __restrict__ trace) {
   // Eight waves, two per SIMD, in two roles (the cell step of k_lstm_mfma split in two):
   //   waves 0-3 (recurrent): acc = gx_t image; acc += W_hh h_{t-1}^T (W_hh fragments in VGPRs); lane-local cell
   //                          update; h_t -> LDS.  Only this is on the recurrence's critical path.
@@ -311,6 +312,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   };
 
   for (int u = blockIdx.x; u < K * V; u += gridDim.x) {
+  // trace (diagnostics, ffd_lstm_trace; nullptr otherwise): per unit {real time at its start, after its start-up (barrier
+  // C), at its end, ticks spent waiting on progress words | workgroup << 48}, 100 MHz ticks, written by one lane
+  const unsigned long long tr0 = trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  unsigned long long tr1 = 0ull, tr_wait = 0ull;
   const int kc = u / V, rem = u - kc * V;
   const int layer = rem / n_tiles, tile = rem - layer * n_tiles;  // (uniform)
   const int tb = kc * T, te = min(L, tb + T);                     // this unit's cell steps [tb, te); tb is even
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
         }
         __builtin_amdgcn_s_sleep(4);
       }
+      if (trace) tr_wait += __builtin_amdgcn_s_memrealtime() - t_start;
     }
   };
   int known = layer > 0 ? 0 : L;  // cell steps the layer below is known to have published
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   __syncthreads();  // B: ring slots 0, 1 written
   input_part(0, 0);
   __syncthreads();  // C
+  if (trace) tr1 = __builtin_amdgcn_s_memrealtime();
   int s0 = 0, s1 = 1, s2 = 2;  // ring slots of x_t, x_{t+1}, x_{t+2} (= the slot x_{t-1} occupied)
   for (int t = tb; t < te; ++t) {
     const int cur = t & 1;
@@ -542,6 +549,10 @@ __global__ __launch_bounds__(512, 2) void k_lstm_wave(float* __restrict__ x, Lst
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tg == 0 && !mute) __hip_atomic_store(my_prog, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (trace && tg == 0) {
+    unsigned long long* o = trace + 4 * (size_t)u;
+    o[0] = tr0, o[1] = tr1, o[2] = __builtin_amdgcn_s_memrealtime(), o[3] = tr_wait | ((unsigned long long)blockIdx.x << 48);
+  }
   }  // units
 }
 
@@ -619,7 +630,8 @@ size_t lstm_wave_state_floats(int B, int D, int NL) {
 
 template <int D>
 static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const float* const* whh, const float* const* bsum,
-                                     int NL, int B, int L, int* prog_all, float* state, int* err, hipStream_t s) {
+                                     int NL, int B, int L, int* prog_all, float* state, int* err, hipStream_t s,
+                                     unsigned long long* trace) {
   int* abort_word = prog_all;  // word 0 of the buffer; the progress words start one 64-byte line further
   int* prog = prog_all + 16;
   const unsigned spin_ticks = (unsigned)g_lstm_wave_spin_ms * 100000u;  // 100 MHz ticks
@@ -645,7 +657,7 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
         hipError_t e = hipMemsetAsync(prog_all, 0, sizeof(int) * (16 + (size_t)n1 * n_tiles), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_lstm_wave<D>), dim3(n1 * n_tiles), dim3(512), lds, s, x, wa, n1, n_tiles, Lfull, B, L, prog,
-                           (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault);
+                           (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault, trace);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
       }
@@ -678,7 +690,7 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
     hipError_t e = hipMemsetAsync(prog_all, 0, sizeof(int) * (16 + (size_t)nl * n_tiles), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_lstm_wave<D>), dim3(P), dim3(512), lds, s, x, wa, nl, n_tiles, chunked ? Tc : Lfull, B, L, prog,
-                       chunked ? state : (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault);
+                       chunked ? state : (float*)nullptr, err, abort_word, spin_ticks, g_lstm_wave_fault, trace);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -686,12 +698,12 @@ static hipError_t launch_lstm_wave_t(float* x, const float* const* wih, const fl
 }
 
 hipError_t launch_lstm_wave(float* x, const float* const* wih, const float* const* whh, const float* const* bsum, int NL,
-                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s) {
+                            int B, int L, int D, int* prog, float* state, int* err, hipStream_t s, unsigned long long* trace) {
   if (B <= 0 || NL <= 0) return hipSuccess;
   if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (size_t)B * L * D * 4 >= (1ull << 31) || err == nullptr) return hipErrorInvalidValue;
   switch (D) {
 #define X(d) \
-  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, err, s);
+  case d: return launch_lstm_wave_t<d>(x, wih, whh, bsum, NL, B, L, prog, state, err, s, trace);
     X(16) X(24) X(32) X(48) X(60) X(64) X(72)
 #undef X
     default: return hipErrorInvalidValue;

@@ -371,6 +371,14 @@ enum {
   FFD_K_UNEMBED = 7,
   FFD_K_COUNT = 8
 };
+/* Diagnostics of the LSTM layer wavefront (k_lstm_wave): with host_out == NULL, arm a trace of `capacity_units` units --
+ * the k_lstm_wave launches of the next forward passes (first sub-batch each) then write four 64-bit words per work unit
+ * (chunk, layer, tile), unit index = chunk * layers * tiles + layer * tiles + tile: 100 MHz real-time ticks at the unit's
+ * start, after its start-up (weights, state, first rows in), at its end, and [47:0] ticks spent waiting on progress words
+ * | workgroup << 48.  With host_out != NULL: synchronise, copy the records out (n_units_out = how many), disarm.  The
+ * capacity must cover chunks * layers * ceil(B / 16) units of the traced launch. */
+int ffd_lstm_trace(ffd_ctx* ctx, unsigned long long* host_out, int capacity_units, int* n_units_out);
+
 /* In-situ timing: between _begin and _end every launch of a kernel whose class bit is set in
  * `class_mask`, issued by forward / sample calls on this context, is bracketed by a HIP event pair
  * on the launch stream (up to max_launches pairs in total); _end synchronises; _get returns the mean

@@ -1462,6 +1462,37 @@ def test_tile_height_form_agrees_with_the_other_forms(ffd, name, batches):
         assert lib.ffd_tune(b"reset", 0) == 0
 
 
+def test_lstm_trace_records_every_unit(ffd):
+    """ffd_lstm_trace (diagnostics): one record per (chunk, layer, tile) unit of the traced k_lstm_wave launch -- start <=
+    start-up done <= end, waits inside the unit's duration, layer l never starts before layer l - 1 of its tile and chunk;
+    the traced forward returns the same scores as an untraced one (bit for bit)."""
+    from fastfourierdiffusion_amd import _native as N
+
+    c = next(c for c in cases.MODEL_CASES if c["name"] == "nasa_lstm")
+    m, _ = make_model(ffd, c)
+    ctx = m._ctx()
+    B, NL = 40, c["NL"]
+    x = torch.from_numpy(next(synthetic.noise_stream((B, c["L"], c["C"]), 1, 99))).cuda()
+    ref = m(batch_of(x, 0.5))
+    tiles = -(-B // 16)
+    cap = NL * tiles
+    N.check(ctx.lib.ffd_lstm_trace(ctx.handle, None, cap, None), ctx.handle, "arm")
+    got = m(batch_of(x, 0.5))
+    raw = (C_.c_uint64 * (4 * cap))()
+    n = C_.c_int()
+    N.check(ctx.lib.ffd_lstm_trace(ctx.handle, raw, cap, C_.byref(n)), ctx.handle, "read")
+    assert torch.equal(got, ref) and n.value == cap
+    r = np.frombuffer(raw, dtype=np.uint64).reshape(cap, 4).astype(np.int64)
+    wait = r[:, 3] & ((1 << 48) - 1)
+    assert (r[:, 0] > 0).all() and (r[:, 0] <= r[:, 1]).all() and (r[:, 1] <= r[:, 2]).all()
+    assert (wait <= r[:, 2] - r[:, 0]).all()
+    start = r[:, 0].reshape(NL, tiles)
+    assert (start[1:] >= start[:-1] - 100).all()  # (all units of this launch are resident: layers start together, +- 1 us)
+    end = r[:, 2].reshape(NL, tiles)
+    assert (end[1:] > end[:-1]).all()  # a layer cannot finish before the one it reads from
+    assert ctx.lib.ffd_lstm_trace(ctx.handle, raw, cap, C_.byref(n)) != 0  # nothing armed: an error, not stale records
+
+
 def test_rows_sliced_form_in_rounds(ffd):
     """Round 4: where tiles x slices exceeds the CUs (ECG B = 384: 187 tiles x 4 slices) the sliced form's workgroups walk
     several tiles of their slice: bit-identical with the one-round result of the same slicing wherever both exist (a
