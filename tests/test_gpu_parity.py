@@ -1416,7 +1416,8 @@ def test_rows_sliced_form_agrees_with_the_other_forms(ffd, name, batches):
         assert rel_err(auto.cpu(), ref.cpu()) < 2e-6, B
 
 
-@pytest.mark.parametrize("name,batches", [("ecg", (13, 20, 32, 40, 50, 64)), ("syn", (5, 7, 12, 20))])
+@pytest.mark.parametrize("name,batches", [("ecg", (13, 20, 32, 40, 50, 64)), ("syn", (5, 7, 12, 20)),
+                                          ("reftest", (60, 120, 200)), ("small", (150, 300, 500))])
 def test_tile_height_form_agrees_with_the_other_forms(ffd, name, batches):
     """Where the 16-row tiles are 1.4 - 3 per CU (ECG: B = 30 ... 65, the reference's default sample_batch_size of 50
     among them) the feed-forward block runs as k_linear_res_ln + k_ffn_ln at 32 / 48 rows per workgroup, one tile per
