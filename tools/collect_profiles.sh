@@ -30,6 +30,10 @@ bash $R/tools/collect_traffic.sh nasa_lstm:512 --workload nasa_lstm --batch 512 
 cp $R/gpurun_out/traffic/r04_traffic.json $O/r04_traffic.json
 python3 $R/tools/batch_sweep.py 2>/dev/null | grep '^{"B"' > $O/batch_sweep.txt
 python3 $R/tools/ffn_d_sweep.py 2>/dev/null | grep '^{' > $O/ffn_d_sweep.txt
+python3 $R/tools/batch_sweep.py 8 10 12 16 20 24 28 32 40 44 50 56 64 66 80 100 128 160 200 2>/dev/null | grep '^{"B"' > $O/batch_sweep_small.txt
+python3 $R/tools/sweep_tile_heights.py 28,32,40,44,50,56,64,66 2>/dev/null | grep '^B=' > $O/tile_height_sweep.txt
+python3 $R/tools/lstm_trace.py 512 2>/dev/null | tail -1 > $O/lstm_trace_B512.json
+python3 $R/tools/lstm_trace.py 2048 2>/dev/null | tail -1 > $O/lstm_trace_B2048.json
 python3 $R/tools/attn_phases.py ecg 512 2>/dev/null > $O/attn_phases_ecg512.json
 python3 $R/tools/attn_phases.py syn512 2048 2>/dev/null > $O/attn_phases_syn2048.json
 python3 $R/tools/attn_phases.py ecg 512 0 2>/dev/null > $O/attn_phases_ecg512_pure.json
